@@ -1,0 +1,580 @@
+// capi.hip — the C ABI of libgfasort_hip.so (include/gfasort_hip.h): host tables, the resident
+// context (device mirror of PathIndex + positions + RNG streams) and the one-shot entry points
+// that stand where path_linear_sgd / path_linear_sgd_layout stand in the reference.
+#include "../../include/gfasort_hip.h"
+#include "sgd_device.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace gfs {
+hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                     dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                     dim3 grid, dim3 block, size_t lds, hipStream_t st);
+}
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(GFS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    } while (0)
+
+// ---- host restatements (bit-exact; this TU is built with -ffp-contract=off) ----------------
+static inline int32_t h_sat_i32(double v) {
+    if (v != v) return 0;
+    if (v <= -2147483648.0) return INT32_MIN;
+    if (v >= 2147483647.0) return INT32_MAX;
+    return (int32_t)v;
+}
+static double h_fpp(double a, double b) {                                  // sgd.rs:155-182
+    int32_t e = h_sat_i32(b);
+    uint64_t bits; std::memcpy(&bits, &a, 8);
+    int32_t high = (int32_t)(bits >> 32);
+    int32_t diff = (int32_t)((uint32_t)high - 1072632447u);
+    int32_t new_high = h_sat_i32((b - (double)e) * (double)diff + 1072632447.0);
+    uint64_t fb = ((uint64_t)(uint32_t)new_high) << 32;
+    double frac; std::memcpy(&frac, &fb, 8);
+    double base = a, r = 1.0;
+    int32_t ex = e;
+    if (ex < 0) return std::nan("");     // the reference would loop forever (b < 0 never occurs for theta in [0,1))
+    while (ex != 0) { if (ex & 1) r *= base; base *= base; ex >>= 1; }
+    return r * frac;
+}
+static uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static int check_params(const gfs_sgd_params *p) {
+    if (!p) return fail(GFS_E_ARG, "params is null");
+    if (!(p->theta >= 0.0 && p->theta < 1.0)) return fail(GFS_E_ARG, "theta must be in [0,1)");
+    if (p->space_quantization_step == 0) return fail(GFS_E_ARG, "space_quantization_step must be > 0");
+    if (!(p->eta_max > 0.0)) return fail(GFS_E_ARG, "eta_max must be > 0");
+    return GFS_OK;
+}
+
+extern "C" {
+
+const char *gfs_version(void) { return "gfasort_hip 0.1.0 (gfx950)"; }
+const char *gfs_last_error(void) { return g_err.c_str(); }
+int gfs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+double gfs_fast_precise_pow(double a, double b) { return h_fpp(a, b); }
+
+int gfs_sgd_schedule(const gfs_sgd_params *p, double *etas) {              // sgd.rs:300-308,617-638
+    if (!p || !etas) return fail(GFS_E_ARG, "null argument");
+    double w_min = 1.0 / p->eta_max, w_max = 1.0;
+    double eta_max = 1.0 / w_min;
+    double eta_min = p->eps / w_max;
+    double lambda = std::log(eta_max / eta_min) / ((double)p->iter_max - 1.0);
+    for (uint64_t t = 0; t <= p->iter_max; ++t) {
+        int64_t d = (int64_t)t - (int64_t)p->iter_with_max_learning_rate;
+        if (d < 0) d = -d;
+        etas[t] = eta_max * std::exp(-lambda * (double)d);
+    }
+    return GFS_OK;
+}
+
+uint64_t gfs_zeta_table_len(const gfs_sgd_params *p) {                     // sgd.rs:311-315
+    if (!p || p->space_quantization_step == 0) return 0;
+    uint64_t n = p->space <= p->space_max
+                     ? p->space
+                     : p->space_max + (p->space - p->space_max) / p->space_quantization_step + 1;
+    return n + 1;
+}
+
+int gfs_zeta_table(const gfs_sgd_params *p, double *zetas) {               // sgd.rs:317-331
+    if (!p || !zetas) return fail(GFS_E_ARG, "null argument");
+    uint64_t len = gfs_zeta_table_len(p);
+    if (!len) return fail(GFS_E_ARG, "bad zeta parameters");
+    for (uint64_t k = 0; k < len; ++k) zetas[k] = 0.0;
+    double zeta_tmp = 0.0;
+    for (uint64_t i = 1; i <= p->space; ++i) {
+        zeta_tmp += h_fpp(1.0 / (double)i, p->theta);
+        if (i <= p->space_max) zetas[i] = zeta_tmp;
+        if (i >= p->space_max && (i - p->space_max) % p->space_quantization_step == 0) {
+            uint64_t idx = p->space_max + 1 + (i - p->space_max) / p->space_quantization_step;
+            if (idx < len) zetas[idx] = zeta_tmp;
+        }
+    }
+    return GFS_OK;
+}
+
+int gfs_init_positions(const gfs_graph_view *g, double *x) {               // sgd.rs:271-294
+    if (!g || (!x && g->n_nodes)) return fail(GFS_E_ARG, "null argument");
+    uint64_t len = 0;
+    for (uint64_t i = 0; i < g->n_nodes; ++i) { x[i] = (double)len; len += g->node_len[i]; }
+    return GFS_OK;
+}
+
+int gfs_init_layout_dim0(const gfs_graph_view *g, uint64_t D, double *c) { // sgd.rs:832-853
+    if (!g || (!c && g->n_nodes) || D == 0) return fail(GFS_E_ARG, "bad argument");
+    uint64_t len = 0;
+    for (uint64_t i = 0; i < g->n_nodes; ++i) {
+        c[i * 2 * D + 0] = (double)len;
+        c[i * 2 * D + D] = (double)(len + g->node_len[i]);
+        len += g->node_len[i];
+    }
+    return GFS_OK;
+}
+
+int gfs_sort_order(const double *x, uint64_t n, uint64_t *order) {         // sgd.rs:665-671
+    if ((!x || !order) && n) return fail(GFS_E_ARG, "null argument");
+    std::iota(order, order + n, (uint64_t)0);
+    // partial_cmp(..).unwrap_or(Equal): a NaN compares Equal to everything; stable; ties by idx
+    std::stable_sort(order, order + n, [x](uint64_t a, uint64_t b) { return x[a] < x[b]; });
+    return GFS_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// resident context
+// ---------------------------------------------------------------------------------------------
+struct gfs_ctx {
+    int device = 0;
+    int cu_count = 0;
+    uint64_t n_nodes = 0, n_steps = 0, n_paths = 0;
+    uint32_t max_path_steps = 0;
+    bool valid_paths = false;
+    // device mirror of PathIndex
+    uint4 *d_step_rec = nullptr;
+    uint4 *d_path_rec = nullptr;
+    uint64_t *d_path_len = nullptr;
+    // SGD state
+    int dims = 0;                      // 0 = 1D
+    bool configured = false;
+    gfs_sgd_params params{};
+    gfs_launch_config cfg{};
+    std::vector<double> etas;
+    double *d_zetas = nullptr; uint64_t zlen_full = 0, zlen_staged = 0;
+    double *d_x = nullptr; bool x_owned = false; uint64_t x_len = 0;
+    uint64_t *d_rng = nullptr;
+    unsigned long long *d_counters = nullptr;
+    gfs_term *d_trace = nullptr; uint32_t *d_trace_cnt = nullptr;
+    uint64_t n_streams = 0, quota_total = 0;
+    uint32_t block = 256;
+    bool lds_tables = true, atomic_loads = true;
+    size_t lds_bytes = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    uint64_t iterations = 0;
+    double total_ms = 0.0;
+};
+
+static void free_sgd_state(gfs_ctx *c) {
+    if (c->d_zetas) (void)hipFree(c->d_zetas);
+    if (c->d_x && c->x_owned) (void)hipFree(c->d_x);
+    if (c->d_rng) (void)hipFree(c->d_rng);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_trace) (void)hipFree(c->d_trace);
+    if (c->d_trace_cnt) (void)hipFree(c->d_trace_cnt);
+    c->d_zetas = nullptr; c->d_x = nullptr; c->d_rng = nullptr; c->d_counters = nullptr;
+    c->d_trace = nullptr; c->d_trace_cnt = nullptr; c->x_owned = false; c->configured = false;
+}
+
+static int seed_streams(gfs_ctx *c) {
+    // stream t <- Xoshiro256Plus::seed_from_u64(seed + stream_base + t)   (sgd.rs:431-432)
+    const uint64_t T = c->n_streams;
+    std::vector<uint64_t> st(4 * T);
+    for (uint64_t t = 0; t < T; ++t) {
+        uint64_t sm = c->params.seed + c->cfg.stream_base + t;
+        for (int k = 0; k < 4; ++k) st[(uint64_t)k * T + t] = splitmix64(sm);
+    }
+    HIPCHK(hipMemcpy(c->d_rng, st.data(), st.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long)));
+    if (c->d_trace_cnt) HIPCHK(hipMemset(c->d_trace_cnt, 0, T * sizeof(uint32_t)));
+    c->events_used = 0; c->iterations = 0; c->total_ms = 0.0;
+    return GFS_OK;
+}
+
+static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs_launch_config *cfg,
+                        const double *etas, const double *zetas) {
+    if (!c) return fail(GFS_E_ARG, "ctx is null");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (dims < 0 || dims > GFS_MAX_DIMS) return fail(GFS_E_UNSUPPORTED, "dimensions must be 1..8");
+    HIPCHK(hipSetDevice(c->device));
+    free_sgd_state(c);
+    c->params = *p;
+    c->cfg = cfg ? *cfg : gfs_launch_config{};
+    c->dims = dims;
+    if (!c->valid_paths || c->n_nodes == 0) { c->configured = true; return GFS_NOTHING_TO_DO; }
+
+    // eta schedule and zeta table (host, bit-exact) unless supplied
+    c->etas.resize(p->iter_max + 1);
+    if (etas) std::copy(etas, etas + p->iter_max + 1, c->etas.begin());
+    else gfs_sgd_schedule(p, c->etas.data());
+    c->zlen_full = gfs_zeta_table_len(p);
+    if (c->zlen_full > 0xFFFFFFFFull) return fail(GFS_E_UNSUPPORTED, "zeta table too long");
+    // Only indices reachable from jump <= min(space, max_path_steps-1) are ever read (sgd.rs:462-469)
+    {
+        uint64_t maxjump = std::min<uint64_t>(p->space, c->max_path_steps ? c->max_path_steps - 1 : 0);
+        uint64_t idx = maxjump > p->space_max
+                           ? p->space_max + (maxjump - p->space_max) / p->space_quantization_step + 1
+                           : maxjump;
+        c->zlen_staged = std::min<uint64_t>(idx + 1, c->zlen_full);
+    }
+    {
+        std::vector<double> ztab;
+        const double *zsrc = zetas;
+        if (!zsrc) {
+            // the running sum is order-dependent: compute the prefix that is reachable, exactly as
+            // the reference accumulates it (entries beyond zlen_staged are never read)
+            gfs_sgd_params q = *p;
+            ztab.resize(c->zlen_full);
+            // cap the summation at the largest i that feeds a staged entry
+            uint64_t need_i = c->zlen_staged <= p->space_max + 1
+                                  ? c->zlen_staged - 1
+                                  : p->space_max + (c->zlen_staged - 1 - p->space_max - 1) * p->space_quantization_step;
+            q.space = std::min<uint64_t>(p->space, std::max<uint64_t>(need_i, 1));
+            std::vector<double> part(gfs_zeta_table_len(&q));
+            gfs_zeta_table(&q, part.data());
+            std::fill(ztab.begin(), ztab.end(), 0.0);
+            std::copy(part.begin(), part.begin() + std::min<size_t>(part.size(), ztab.size()), ztab.begin());
+            zsrc = ztab.data();
+            HIPCHK(hipMalloc(&c->d_zetas, c->zlen_full * 8));
+            HIPCHK(hipMemcpy(c->d_zetas, zsrc, c->zlen_full * 8, hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(hipMalloc(&c->d_zetas, c->zlen_full * 8));
+            HIPCHK(hipMemcpy(c->d_zetas, zsrc, c->zlen_full * 8, hipMemcpyHostToDevice));
+        }
+    }
+
+    // positions
+    c->x_len = dims ? c->n_nodes * 2 * (uint64_t)dims : c->n_nodes;
+    HIPCHK(hipMalloc(&c->d_x, c->x_len * 8));
+    HIPCHK(hipMemset(c->d_x, 0, c->x_len * 8));
+    c->x_owned = true;
+
+    // launch shape
+    c->quota_total = c->cfg.term_updates_per_iteration ? c->cfg.term_updates_per_iteration : p->min_term_updates;
+    c->block = c->cfg.block_size ? c->cfg.block_size : 256;
+    if (c->block % 64 || c->block > 1024) return fail(GFS_E_ARG, "block_size must be a multiple of 64, <= 1024");
+    uint64_t T = c->cfg.n_streams;
+    if (T == 0) {
+        // fill the chip (2048 resident lanes per CU) but keep >= 8 updates per stream per batch
+        uint64_t chip = (uint64_t)c->cu_count * 2048;
+        uint64_t want = (c->quota_total + 7) / 8;
+        T = std::max<uint64_t>(64, std::min<uint64_t>(chip, (want + 63) / 64 * 64));
+    }
+    if (T > 0x7FFFFFFFull) return fail(GFS_E_ARG, "n_streams too large");
+    c->n_streams = T;
+    if (c->quota_total / T + 1 > 0xFFFFFFFFull) return fail(GFS_E_UNSUPPORTED, "per-stream quota exceeds 2^32");
+    if (c->cfg.attempt_factor == 0) c->cfg.attempt_factor = 64;
+    if (c->cfg.attempt_factor > 0xFFFFFFFFull) return fail(GFS_E_ARG, "attempt_factor too large");
+    c->atomic_loads = !(c->cfg.flags & GFS_F_PLAIN_LOADS);
+    size_t lds = (size_t)c->n_paths * sizeof(uint4) + (size_t)c->zlen_staged * 8;
+    c->lds_tables = !(c->cfg.flags & GFS_F_NO_LDS_TABLES) && lds <= 48 * 1024;
+    c->lds_bytes = c->lds_tables ? lds : 0;
+
+    HIPCHK(hipMalloc(&c->d_rng, 4 * T * 8));
+    HIPCHK(hipMalloc(&c->d_counters, 2 * sizeof(unsigned long long)));
+    if (c->cfg.trace_per_stream) {
+        HIPCHK(hipMalloc(&c->d_trace, T * c->cfg.trace_per_stream * sizeof(gfs_term)));
+        HIPCHK(hipMemset(c->d_trace, 0, T * c->cfg.trace_per_stream * sizeof(gfs_term)));
+        HIPCHK(hipMalloc(&c->d_trace_cnt, T * sizeof(uint32_t)));
+    }
+    rc = seed_streams(c);
+    if (rc) return rc;
+    c->configured = true;
+    return GFS_OK;
+}
+
+static void iter_consts(const gfs_ctx *c, uint64_t k, gfs::IterConsts &it) {
+    const gfs_sgd_params &p = c->params;
+    double fc = std::floor(p.cooling_start * (double)p.iter_max);          // sgd.rs:297
+    uint64_t first_cooling = !(fc > 0.0) ? 0 : (fc >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)fc);
+    bool cooling = k > first_cooling;                                      // sgd.rs:393-396
+    double theta = cooling ? 0.001 : p.theta;
+    it.eta = c->etas[k];
+    it.cooling = cooling ? 1 : 0;
+    it.zeta2theta = 1.0 + h_fpp(0.5, theta);                               // sgd.rs:471 (== :143 bound)
+    double omt = 1.0 - theta;                                              // sgd.rs:133
+    it.omt_e = h_sat_i32(omt); it.omt_fb = omt - (double)it.omt_e;
+    double alpha = 1.0 / (1.0 - theta);                                    // sgd.rs:132
+    it.alpha_e = h_sat_i32(alpha); it.alpha_fb = alpha - (double)it.alpha_e;
+    it._pad = 0;
+}
+
+extern "C" {
+
+int gfs_ctx_create(const gfs_graph_view *g, int device, gfs_ctx **out) {
+    if (!g || !out) return fail(GFS_E_ARG, "null argument");
+    *out = nullptr;
+    if (g->n_steps > 0xFFFFFFFEull) return fail(GFS_E_UNSUPPORTED, "more than 2^32-2 path steps");
+    if (g->n_nodes > 0x7FFFFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^31-1 nodes");
+    if (g->n_paths > 0x7FFFFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^31-1 paths");
+    if (g->n_steps && (!g->step_node || !g->step_is_rev)) return fail(GFS_E_ARG, "null step arrays");
+    if (!g->path_first_step) return fail(GFS_E_ARG, "null path_first_step");
+    if (g->n_nodes && !g->node_len) return fail(GFS_E_ARG, "null node_len");
+    if (g->path_first_step[0] != 0 || g->path_first_step[g->n_paths] != g->n_steps)
+        return fail(GFS_E_ARG, "path_first_step must start at 0 and end at n_steps");
+    for (uint64_t p = 0; p < g->n_paths; ++p)
+        if (g->path_first_step[p + 1] < g->path_first_step[p]) return fail(GFS_E_ARG, "path_first_step not monotone");
+    for (uint64_t s = 0; s < g->n_steps; ++s)
+        if (g->step_node[s] != GFS_NO_NODE && g->step_node[s] >= g->n_nodes)
+            return fail(GFS_E_ARG, "step_node out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(GFS_E_HIP, "no HIP device available (libgfasort_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GFS_E_ARG, "bad device index");
+    gfs_ctx *c = new (std::nothrow) gfs_ctx();
+    if (!c) return fail(GFS_E_NOMEM, "out of memory");
+    c->device = device;
+    c->n_nodes = g->n_nodes; c->n_steps = g->n_steps; c->n_paths = g->n_paths;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete c; return fail(GFS_E_HIP, "hipGetDeviceProperties failed");
+    }
+    c->cu_count = prop.multiProcessorCount;
+
+    // PathIndex::from_graph (sgd.rs:34-71) into 16-byte records
+    std::vector<uint4> rec(std::max<uint64_t>(g->n_steps, 1));
+    std::vector<uint4> prec(std::max<uint64_t>(g->n_paths, 1));
+    std::vector<uint64_t> plen(std::max<uint64_t>(g->n_paths, 1));
+    for (uint64_t p = 0; p < g->n_paths; ++p) {
+        uint64_t b = g->path_first_step[p], e = g->path_first_step[p + 1];
+        uint64_t position = 0;
+        for (uint64_t s = b; s < e; ++s) {
+            uint32_t n = g->step_node[s];
+            rec[s].x = n;
+            rec[s].y = (uint32_t)p | ((uint32_t)(g->step_is_rev[s] & 1) << 31);
+            rec[s].z = (uint32_t)position; rec[s].w = (uint32_t)(position >> 32);
+            if (n != GFS_NO_NODE) position += g->node_len[n];
+        }
+        uint32_t cnt = (uint32_t)(e - b);
+        prec[p].x = (uint32_t)b; prec[p].y = cnt;
+        prec[p].z = cnt ? (uint32_t)(0u - cnt) % cnt : 0u; prec[p].w = 0;
+        plen[p] = position;
+        if (cnt > 1) c->valid_paths = true;                               // sgd.rs:250-256
+        c->max_path_steps = std::max(c->max_path_steps, cnt);
+    }
+    auto bail = [&](const char *what, hipError_t e) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(e);
+        gfs_ctx_destroy(c);
+        return fail(GFS_E_HIP, m);
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&c->d_step_rec, rec.size() * sizeof(uint4))) != hipSuccess) return bail("hipMalloc step_rec", e);
+    if ((e = hipMalloc(&c->d_path_rec, prec.size() * sizeof(uint4))) != hipSuccess) return bail("hipMalloc path_rec", e);
+    if ((e = hipMalloc(&c->d_path_len, plen.size() * 8)) != hipSuccess) return bail("hipMalloc path_len", e);
+    if ((e = hipMemcpy(c->d_step_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy step_rec", e);
+    if ((e = hipMemcpy(c->d_path_rec, prec.data(), prec.size() * sizeof(uint4), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy path_rec", e);
+    if ((e = hipMemcpy(c->d_path_len, plen.data(), plen.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy path_len", e);
+    *out = c;
+    return GFS_OK;
+}
+
+void gfs_ctx_destroy(gfs_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_sgd_state(c);
+    for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (c->d_step_rec) (void)hipFree(c->d_step_rec);
+    if (c->d_path_rec) (void)hipFree(c->d_path_rec);
+    if (c->d_path_len) (void)hipFree(c->d_path_len);
+    delete c;
+}
+
+int gfs_ctx_setup_1d(gfs_ctx *c, const gfs_sgd_params *p, const gfs_launch_config *cfg,
+                     const double *etas, const double *zetas) {
+    return setup_common(c, p, 0, cfg, etas, zetas);
+}
+int gfs_ctx_setup_nd(gfs_ctx *c, const gfs_layout_params *p, const gfs_launch_config *cfg,
+                     const double *etas, const double *zetas) {
+    if (!p) return fail(GFS_E_ARG, "params is null");
+    if (p->dimensions < 1 || p->dimensions > GFS_MAX_DIMS) return fail(GFS_E_UNSUPPORTED, "dimensions must be 1..8");
+    return setup_common(c, &p->sgd, (int)p->dimensions, cfg, etas, zetas);
+}
+
+uint64_t gfs_ctx_positions_len(const gfs_ctx *c) { return c ? c->x_len : 0; }
+
+int gfs_ctx_upload_positions(gfs_ctx *c, const double *host, uint64_t n) {
+    if (!c || !host) return fail(GFS_E_ARG, "null argument");
+    if (!c->d_x) return fail(GFS_E_STATE, "context not set up");
+    if (n != c->x_len) return fail(GFS_E_ARG, "positions length mismatch");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->d_x, host, n * 8, hipMemcpyHostToDevice));
+    return GFS_OK;
+}
+int gfs_ctx_download_positions(gfs_ctx *c, double *host, uint64_t n) {
+    if (!c || !host) return fail(GFS_E_ARG, "null argument");
+    if (!c->d_x) return fail(GFS_E_STATE, "context not set up");
+    if (n != c->x_len) return fail(GFS_E_ARG, "positions length mismatch");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host, c->d_x, n * 8, hipMemcpyDeviceToHost));
+    return GFS_OK;
+}
+void *gfs_ctx_positions_device(gfs_ctx *c) { return c ? (void *)c->d_x : nullptr; }
+int gfs_ctx_bind_positions(gfs_ctx *c, void *device_ptr) {
+    if (!c || !device_ptr) return fail(GFS_E_ARG, "null argument");
+    if (!c->configured || !c->x_len) return fail(GFS_E_STATE, "context not set up");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_x && c->x_owned) HIPCHK(hipFree(c->d_x));
+    c->d_x = (double *)device_ptr; c->x_owned = false;
+    return GFS_OK;
+}
+int gfs_ctx_reset_streams(gfs_ctx *c) {
+    if (!c || !c->d_rng) return fail(GFS_E_STATE, "context not set up");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    return seed_streams(c);
+}
+
+int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
+    if (!c) return fail(GFS_E_ARG, "ctx is null");
+    if (!c->configured) return fail(GFS_E_STATE, "context not set up");
+    if (!c->valid_paths || c->n_nodes == 0) return GFS_NOTHING_TO_DO;
+    if (k > c->params.iter_max) return fail(GFS_E_ARG, "iteration beyond iter_max");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    gfs::KArgs a{};
+    a.step_rec = c->d_step_rec; a.path_rec = c->d_path_rec; a.path_len = c->d_path_len;
+    a.zetas = c->d_zetas; a.x = c->d_x; a.rng = c->d_rng; a.counters = c->d_counters;
+    a.trace = c->d_trace; a.trace_cnt = c->d_trace_cnt;
+    a.n_steps = (uint32_t)c->n_steps;
+    a.steps_thresh = (uint32_t)(0u - a.n_steps) % a.n_steps;
+    a.n_paths = (uint32_t)c->n_paths;
+    a.zlen_full = (uint32_t)c->zlen_full; a.zlen_staged = (uint32_t)c->zlen_staged;
+    a.n_streams = (uint32_t)c->n_streams;
+    a.quota_base = (uint32_t)(c->quota_total / c->n_streams);
+    a.quota_rem = (uint32_t)(c->quota_total % c->n_streams);
+    a.attempt_factor = (uint32_t)c->cfg.attempt_factor;
+    a.trace_per_stream = (uint32_t)c->cfg.trace_per_stream;
+    a.space = (uint32_t)std::min<uint64_t>(c->params.space, 0xFFFFFFFFull);
+    a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
+    a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
+    iter_consts(c, k, a.it);
+    dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
+    if (c->events_used == c->events.size()) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        c->events.emplace_back(e0, e1);
+    }
+    auto &ev = c->events[c->events_used++];
+    HIPCHK(hipEventRecord(ev.first, st));
+    hipError_t e = c->dims == 0
+        ? gfs::launch_1d(a, c->lds_tables, c->atomic_loads, c->d_trace != nullptr, grid, block, c->lds_bytes, st)
+        : gfs::launch_nd(c->dims, a, c->lds_tables, c->atomic_loads, c->d_trace != nullptr, grid, block, c->lds_bytes, st);
+    if (e != hipSuccess) return fail(GFS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    HIPCHK(hipEventRecord(ev.second, st));
+    c->iterations++;
+    return GFS_OK;
+}
+
+int gfs_ctx_synchronize(gfs_ctx *c, void *hip_stream) {
+    if (!c) return fail(GFS_E_ARG, "ctx is null");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+    return GFS_OK;
+}
+
+int gfs_ctx_run(gfs_ctx *c, void *hip_stream) {
+    if (!c) return fail(GFS_E_ARG, "ctx is null");
+    if (!c->configured) return fail(GFS_E_STATE, "context not set up");
+    if (!c->valid_paths || c->n_nodes == 0) return GFS_NOTHING_TO_DO;
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t k = 0; k <= c->params.iter_max; ++k) {                   // iter_max+1 batches (sgd.rs:383)
+        int rc = gfs_ctx_run_iteration(c, k, hip_stream);
+        if (rc) return rc;
+    }
+    int rc = gfs_ctx_synchronize(c, hip_stream);
+    if (rc) return rc;
+    c->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return GFS_OK;
+}
+
+int gfs_ctx_stats(gfs_ctx *c, gfs_stats *out) {
+    if (!c || !out) return fail(GFS_E_ARG, "null argument");
+    std::memset(out, 0, sizeof *out);
+    if (!c->d_counters) return GFS_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long cnt[2] = {0, 0};
+    HIPCHK(hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+    out->term_updates = cnt[0]; out->attempts = cnt[1];
+    out->iterations = c->iterations; out->n_streams = c->n_streams;
+    double ms = 0.0;
+    for (size_t k = 0; k < c->events_used; ++k) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, c->events[k].first, c->events[k].second) == hipSuccess) ms += t;
+    }
+    out->kernel_ms = ms; out->total_ms = c->total_ms;
+    return GFS_OK;
+}
+
+int gfs_ctx_trace(gfs_ctx *c, gfs_term *out, uint64_t n_terms, uint64_t *counts, uint64_t n_streams) {
+    if (!c || !out) return fail(GFS_E_ARG, "null argument");
+    if (!c->d_trace) return fail(GFS_E_STATE, "trace_per_stream was 0");
+    if (n_terms != c->n_streams * c->cfg.trace_per_stream) return fail(GFS_E_ARG, "trace length mismatch");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, c->d_trace, n_terms * sizeof(gfs_term), hipMemcpyDeviceToHost));
+    if (counts) {
+        if (n_streams != c->n_streams) return fail(GFS_E_ARG, "counts length mismatch");
+        std::vector<uint32_t> tmp(c->n_streams);
+        HIPCHK(hipMemcpy(tmp.data(), c->d_trace_cnt, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (uint64_t t = 0; t < c->n_streams; ++t) counts[t] = tmp[t];
+    }
+    return GFS_OK;
+}
+
+// ---- one-shot entry points -------------------------------------------------------------------
+static int one_shot(const gfs_graph_view *g, const gfs_sgd_params *p, int dims, const gfs_launch_config *cfg,
+                    const double *etas, const double *zetas, int init_x, double *x, gfs_stats *stats) {
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (!g || !p) return fail(GFS_E_ARG, "null argument");
+    if (g->n_nodes == 0) return GFS_NOTHING_TO_DO;                         // sgd.rs:242-244,780-782
+    if (!x) return fail(GFS_E_ARG, "positions buffer is null");
+    auto t0 = std::chrono::steady_clock::now();
+    gfs_ctx *c = nullptr;
+    int rc = gfs_ctx_create(g, 0, &c);
+    if (rc) return rc;
+    if (dims == 0) rc = gfs_ctx_setup_1d(c, p, cfg, etas, zetas);
+    else { gfs_layout_params lp; lp.dimensions = (uint64_t)dims; lp.sgd = *p; rc = gfs_ctx_setup_nd(c, &lp, cfg, etas, zetas); }
+    if (rc) { gfs_ctx_destroy(c); return rc; }
+    if (dims == 0 && init_x) gfs_init_positions(g, x);
+    rc = gfs_ctx_upload_positions(c, x, gfs_ctx_positions_len(c));
+    if (!rc) rc = gfs_ctx_run(c, nullptr);
+    if (!rc) rc = gfs_ctx_download_positions(c, x, gfs_ctx_positions_len(c));
+    if (!rc && stats) {
+        rc = gfs_ctx_stats(c, stats);
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    gfs_ctx_destroy(c);
+    return rc;
+}
+
+int gfs_path_linear_sgd(const gfs_graph_view *g, const gfs_sgd_params *p, const gfs_launch_config *cfg,
+                        const double *etas, const double *zetas, int init_x, double *x_inout, gfs_stats *stats) {
+    return one_shot(g, p, 0, cfg, etas, zetas, init_x, x_inout, stats);
+}
+
+int gfs_path_linear_sgd_layout(const gfs_graph_view *g, const gfs_layout_params *p, const gfs_launch_config *cfg,
+                               const double *etas, const double *zetas, double *coords_inout, gfs_stats *stats) {
+    if (!p) return fail(GFS_E_ARG, "params is null");
+    if (p->dimensions < 1 || p->dimensions > GFS_MAX_DIMS) return fail(GFS_E_UNSUPPORTED, "dimensions must be 1..8");
+    return one_shot(g, &p->sgd, (int)p->dimensions, cfg, etas, zetas, 0, coords_inout, stats);
+}
+
+}  // extern "C"

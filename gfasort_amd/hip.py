@@ -1,0 +1,297 @@
+"""ctypes binding of libgfasort_hip.so (include/gfasort_hip.h).  There is no CPU fallback:
+if the library is missing this module raises, and compute calls on a machine without a HIP
+device return GFS_E_HIP (raised as GfsError)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+NO_NODE = 0xFFFFFFFF
+MAX_DIMS = 8
+OK, NOTHING_TO_DO = 0, 1
+F_PLAIN_LOADS, F_NO_LDS_TABLES = 1, 2
+
+
+class GfsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gfasort_hip error {code}: {msg}")
+        self.code = code
+
+
+class GraphView(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_steps", C.c_uint64), ("n_paths", C.c_uint64),
+                ("node_len", C.c_void_p), ("step_node", C.c_void_p),
+                ("step_is_rev", C.c_void_p), ("path_first_step", C.c_void_p)]
+
+
+class SgdParams(C.Structure):
+    _fields_ = [("iter_max", C.c_uint64), ("iter_with_max_learning_rate", C.c_uint64),
+                ("min_term_updates", C.c_uint64), ("delta", C.c_double), ("eps", C.c_double),
+                ("eta_max", C.c_double), ("theta", C.c_double), ("space", C.c_uint64),
+                ("space_max", C.c_uint64), ("space_quantization_step", C.c_uint64),
+                ("cooling_start", C.c_double), ("nthreads", C.c_uint64),
+                ("progress", C.c_uint8), ("_pad", C.c_uint8 * 7), ("seed", C.c_uint64)]
+
+
+class LayoutParams(C.Structure):
+    _fields_ = [("dimensions", C.c_uint64), ("sgd", SgdParams)]
+
+
+class LaunchConfig(C.Structure):
+    _fields_ = [("n_streams", C.c_uint64), ("stream_base", C.c_uint64),
+                ("term_updates_per_iteration", C.c_uint64), ("attempt_factor", C.c_uint64),
+                ("block_size", C.c_uint32), ("flags", C.c_uint32), ("trace_per_stream", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("term_updates", C.c_uint64), ("attempts", C.c_uint64), ("iterations", C.c_uint64),
+                ("n_streams", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)
+
+# every symbol include/gfasort_hip.h declares
+EXPORTS = [
+    "gfs_version", "gfs_last_error", "gfs_device_count", "gfs_fast_precise_pow", "gfs_sgd_schedule",
+    "gfs_zeta_table_len", "gfs_zeta_table", "gfs_init_positions", "gfs_init_layout_dim0",
+    "gfs_sort_order", "gfs_path_linear_sgd", "gfs_path_linear_sgd_layout", "gfs_ctx_create",
+    "gfs_ctx_destroy", "gfs_ctx_setup_1d", "gfs_ctx_setup_nd", "gfs_ctx_positions_len",
+    "gfs_ctx_upload_positions", "gfs_ctx_download_positions", "gfs_ctx_positions_device",
+    "gfs_ctx_bind_positions", "gfs_ctx_reset_streams", "gfs_ctx_run_iteration", "gfs_ctx_run",
+    "gfs_ctx_synchronize", "gfs_ctx_stats", "gfs_ctx_trace",
+]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    """Load libgfasort_hip.so; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is not built: run `python -m gfasort_amd.build` "
+                              "(hipcc, gfx950). There is no CPU fallback.")
+        L = C.CDLL(path)
+        L.gfs_version.restype = C.c_char_p
+        L.gfs_last_error.restype = C.c_char_p
+        L.gfs_fast_precise_pow.restype = C.c_double
+        L.gfs_fast_precise_pow.argtypes = [C.c_double, C.c_double]
+        L.gfs_zeta_table_len.restype = C.c_uint64
+        L.gfs_ctx_positions_len.restype = C.c_uint64
+        L.gfs_ctx_positions_len.argtypes = [C.c_void_p]
+        L.gfs_ctx_positions_device.restype = C.c_void_p
+        L.gfs_ctx_positions_device.argtypes = [C.c_void_p]
+        L.gfs_ctx_destroy.argtypes = [C.c_void_p]
+        L.gfs_ctx_destroy.restype = None
+        L.gfs_ctx_run_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.gfs_ctx_run.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_ctx_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_ctx_bind_positions.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_ctx_reset_streams.argtypes = [C.c_void_p]
+        L.gfs_ctx_upload_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.gfs_ctx_download_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.gfs_ctx_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_ctx_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.gfs_ctx_setup_1d.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.gfs_ctx_setup_nd.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.gfs_sort_order.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise GfsError(rc, lib().gfs_last_error().decode())
+    return rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_view(g):
+    """gfs_graph_view over a FlatGraph; returns (view, keepalive)."""
+    arrs = (np.ascontiguousarray(g.node_len, dtype=np.uint32),
+            np.ascontiguousarray(g.step_node, dtype=np.uint32),
+            np.ascontiguousarray(g.step_is_rev, dtype=np.uint8),
+            np.ascontiguousarray(g.path_first_step, dtype=np.uint64))
+    v = GraphView(g.n_nodes, g.n_steps, g.n_paths, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]))
+    return v, arrs
+
+
+def make_sgd_params(p):
+    s = SgdParams()
+    for name in ("iter_max", "iter_with_max_learning_rate", "min_term_updates", "delta", "eps", "eta_max",
+                 "theta", "space", "space_max", "space_quantization_step", "cooling_start", "nthreads", "seed"):
+        setattr(s, name, getattr(p, name))
+    s.progress = 1 if p.progress else 0
+    return s
+
+
+def make_layout_params(p):
+    lp = LayoutParams()
+    lp.dimensions = p.dimensions
+    lp.sgd = make_sgd_params(p)
+    return lp
+
+
+def make_config(n_streams=0, stream_base=0, term_updates_per_iteration=0, attempt_factor=0,
+                block_size=0, flags=0, trace_per_stream=0):
+    return LaunchConfig(n_streams, stream_base, term_updates_per_iteration, attempt_factor,
+                        block_size, flags, trace_per_stream)
+
+
+# ---- host tables -----------------------------------------------------------------------------
+def fast_precise_pow(a, b):
+    return lib().gfs_fast_precise_pow(a, b)
+
+
+def sgd_schedule(p):
+    sp = make_sgd_params(p)
+    etas = np.zeros(p.iter_max + 1, dtype=np.float64)
+    check(lib().gfs_sgd_schedule(C.byref(sp), _ptr(etas)))
+    return etas
+
+
+def zeta_table(p):
+    sp = make_sgd_params(p)
+    n = lib().gfs_zeta_table_len(C.byref(sp))
+    z = np.zeros(n, dtype=np.float64)
+    check(lib().gfs_zeta_table(C.byref(sp), _ptr(z)))
+    return z
+
+
+def init_positions(g):
+    v, keep = make_view(g)
+    x = np.zeros(g.n_nodes, dtype=np.float64)
+    check(lib().gfs_init_positions(C.byref(v), _ptr(x)))
+    return x
+
+
+def init_layout_dim0(g, dims, coords=None):
+    v, keep = make_view(g)
+    if coords is None:
+        coords = np.zeros(g.n_nodes * 2 * dims, dtype=np.float64)
+    check(lib().gfs_init_layout_dim0(C.byref(v), C.c_uint64(dims), _ptr(coords)))
+    return coords
+
+
+def sort_order(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    order = np.zeros(x.shape[0], dtype=np.uint64)
+    check(lib().gfs_sort_order(_ptr(x), x.shape[0], _ptr(order)))
+    return order
+
+
+# ---- resident context ------------------------------------------------------------------------
+class Context:
+    """gfs_ctx: the graph's PathIndex mirror, positions and RNG streams resident in HBM."""
+
+    def __init__(self, g, device=0):
+        self._h = C.c_void_p()
+        self.graph = g
+        v, self._keep = make_view(g)
+        check(lib().gfs_ctx_create(C.byref(v), C.c_int(device), C.byref(self._h)))
+        self.dims = 0
+        self.params = None
+        self.cfg = None
+
+    def close(self):
+        if self._h:
+            lib().gfs_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setup_1d(self, p, cfg=None, etas=None, zetas=None):
+        sp = make_sgd_params(p)
+        self.params, self.cfg, self.dims = p, cfg, 0
+        return check(lib().gfs_ctx_setup_1d(self._h, C.byref(sp), C.byref(cfg) if cfg is not None else None,
+                                            _ptr(etas), _ptr(zetas)))
+
+    def setup_nd(self, p, cfg=None, etas=None, zetas=None):
+        lp = make_layout_params(p)
+        self.params, self.cfg, self.dims = p, cfg, p.dimensions
+        return check(lib().gfs_ctx_setup_nd(self._h, C.byref(lp), C.byref(cfg) if cfg is not None else None,
+                                            _ptr(etas), _ptr(zetas)))
+
+    def positions_len(self):
+        return int(lib().gfs_ctx_positions_len(self._h))
+
+    def upload(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        check(lib().gfs_ctx_upload_positions(self._h, _ptr(x), x.shape[0]))
+
+    def download(self):
+        x = np.zeros(self.positions_len(), dtype=np.float64)
+        check(lib().gfs_ctx_download_positions(self._h, _ptr(x), x.shape[0]))
+        return x
+
+    def positions_device(self):
+        return lib().gfs_ctx_positions_device(self._h)
+
+    def bind_positions(self, device_ptr):
+        check(lib().gfs_ctx_bind_positions(self._h, C.c_void_p(device_ptr)))
+
+    def reset_streams(self):
+        check(lib().gfs_ctx_reset_streams(self._h))
+
+    def run_iteration(self, k, stream=None):
+        return check(lib().gfs_ctx_run_iteration(self._h, C.c_uint64(k), C.c_void_p(stream or 0)))
+
+    def run(self, stream=None):
+        return check(lib().gfs_ctx_run(self._h, C.c_void_p(stream or 0)))
+
+    def synchronize(self, stream=None):
+        check(lib().gfs_ctx_synchronize(self._h, C.c_void_p(stream or 0)))
+
+    def stats(self):
+        st = Stats()
+        check(lib().gfs_ctx_stats(self._h, C.byref(st)))
+        return st
+
+    def trace(self):
+        st = self.stats()
+        k = int(self.cfg.trace_per_stream)
+        T = int(st.n_streams)
+        out = np.zeros(T * k, dtype=TERM_DTYPE)
+        counts = np.zeros(T, dtype=np.uint64)
+        check(lib().gfs_ctx_trace(self._h, _ptr(out), T * k, _ptr(counts), T))
+        return out.reshape(T, k), counts
+
+
+# ---- one-shot entry points ---------------------------------------------------------------------
+def path_linear_sgd_raw(g, p, x=None, cfg=None, etas=None, zetas=None):
+    """gfs_path_linear_sgd.  Returns (rc, x, stats)."""
+    v, keep = make_view(g)
+    sp = make_sgd_params(p)
+    init = 1 if x is None else 0
+    if x is None:
+        x = np.zeros(g.n_nodes, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    st = Stats()
+    rc = check(lib().gfs_path_linear_sgd(C.byref(v), C.byref(sp), C.byref(cfg) if cfg is not None else None,
+                                         _ptr(etas), _ptr(zetas), C.c_int(init), _ptr(x), C.byref(st)))
+    return rc, x, st
+
+
+def path_linear_sgd_layout_raw(g, p, coords, cfg=None, etas=None, zetas=None):
+    """gfs_path_linear_sgd_layout.  coords: float64[n_nodes*2*D] Layout order, updated copy returned."""
+    v, keep = make_view(g)
+    lp = make_layout_params(p)
+    coords = np.ascontiguousarray(coords, dtype=np.float64).copy()
+    st = Stats()
+    rc = check(lib().gfs_path_linear_sgd_layout(C.byref(v), C.byref(lp), C.byref(cfg) if cfg is not None else None,
+                                                _ptr(etas), _ptr(zetas), _ptr(coords), C.byref(st)))
+    return rc, coords, st

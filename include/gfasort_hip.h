@@ -1,0 +1,175 @@
+/*
+ * gfasort_hip.h — C ABI of libgfasort_hip.so: the MI355X (gfx950) path-guided SGD engine that
+ * replaces the inner loops of pangenome/gfasort's `Y` (1D sort) and `L` (nD layout) steps.
+ *
+ * The reference has no FFI; the seam is the pair of Rust functions
+ *     pub fn path_linear_sgd(graph: Arc<BidirectedGraph>, params: PathSGDParams) -> HashMap<usize,f64>
+ *                                                                        (src/sgd.rs:237-240)
+ *     pub fn path_linear_sgd_layout(graph: Arc<BidirectedGraph>, params: LayoutSGDParams) -> Layout
+ *                                                                        (src/sgd.rs:773-776)
+ * and this header is what a Rust `extern "C"` block for that seam binds (INTEGRATION.md shows
+ * the shim).  Plain pointers and sizes only; caller owns every buffer; nothing is retained
+ * after a call returns except inside an explicit gfs_ctx.
+ *
+ * Return codes: 0 ok; 1 nothing to do (empty graph or no path with >1 step: the reference
+ * returns an empty map / zero Layout, sgd.rs:242-244,258-261,780-782,795-798 — leave the graph
+ * untouched); <0 error, text in gfs_last_error().  Never throws or aborts across the boundary.
+ * There is NO CPU fallback: without a HIP device every compute entry point returns GFS_E_HIP.
+ */
+#ifndef GFASORT_HIP_H
+#define GFASORT_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFS_OK            0
+#define GFS_NOTHING_TO_DO 1
+#define GFS_E_ARG        (-1)
+#define GFS_E_HIP        (-2)
+#define GFS_E_NOMEM      (-3)
+#define GFS_E_STATE      (-4)
+#define GFS_E_UNSUPPORTED (-5)
+
+#define GFS_NO_NODE 0xFFFFFFFFu
+#define GFS_MAX_DIMS 8
+
+/* Read-only, caller-owned SoA view of the three things sgd.rs reads from BidirectedGraph
+ * (src/graph_ops.rs:10-16): graph.nodes[*].sequence.len(), graph.paths[*].steps and
+ * graph.node_order.  Dense node index k = k-th existing node of node_order, i.e. the value
+ * the reference stores in handle_to_idx[Handle::forward(id)] (sgd.rs:286-294, 811-814). */
+typedef struct gfs_graph_view {
+    uint64_t        n_nodes;          /* graph.node_count()                       sgd.rs:241 */
+    uint64_t        n_steps;          /* PathIndex::get_total_steps()             sgd.rs:73  */
+    uint64_t        n_paths;          /* PathIndex::num_paths()                   sgd.rs:101 */
+    const uint32_t *node_len;         /* [n_nodes]  sequence.len() by dense index            */
+    const uint32_t *step_node;        /* [n_steps]  dense index of the step's node, or
+                                         GFS_NO_NODE when the id is absent from the graph
+                                         (the reference warns and skips, sgd.rs:525-538)     */
+    const uint8_t  *step_is_rev;      /* [n_steps]  Handle::is_reverse()      graph.rs:37    */
+    const uint64_t *path_first_step;  /* [n_paths+1] PathInfo.first_step; counts by diff     */
+} gfs_graph_view;
+
+/* PathSGDParams, src/sgd.rs:196-212, same field names and order (usize->u64, bool->u8). */
+typedef struct gfs_sgd_params {
+    uint64_t iter_max;
+    uint64_t iter_with_max_learning_rate;
+    uint64_t min_term_updates;
+    double   delta;                   /* carried, unused — as in the reference               */
+    double   eps;
+    double   eta_max;
+    double   theta;
+    uint64_t space;
+    uint64_t space_max;
+    uint64_t space_quantization_step;
+    double   cooling_start;
+    uint64_t nthreads;                /* CPU concept; ignored by the HIP engine              */
+    uint8_t  progress;
+    uint8_t  _pad[7];
+    uint64_t seed;
+} gfs_sgd_params;
+
+/* LayoutSGDParams, src/sgd.rs:676-707. */
+typedef struct gfs_layout_params {
+    uint64_t dimensions;              /* 1..GFS_MAX_DIMS                                     */
+    gfs_sgd_params sgd;               /* the remaining 14 fields are identical               */
+} gfs_layout_params;
+
+/* Device-side launch shape (no reference equivalent; the reference's analogue is nthreads).
+ * A "stream" is one Xoshiro256+ generator seeded seed + stream_base + t, exactly what
+ * reference worker thread tid = stream_base + t uses (sgd.rs:431-432); one GPU lane owns one
+ * stream.  All-zero = defaults. */
+typedef struct gfs_launch_config {
+    uint64_t n_streams;               /* 0 = auto (fill the chip, >= 1 update per stream)    */
+    uint64_t stream_base;             /* first global stream id on this device (multi-GPU)   */
+    uint64_t term_updates_per_iteration; /* 0 = params.min_term_updates (this device's share) */
+    uint64_t attempt_factor;          /* 0 = 64: a stream gives up an iteration after
+                                         attempt_factor*quota+1024 sampled-and-rejected trips */
+    uint32_t block_size;              /* 0 = 256                                             */
+    uint32_t flags;                   /* GFS_F_*                                             */
+    uint64_t trace_per_stream;        /* debug: keep the first k successful terms per stream */
+} gfs_launch_config;
+
+#define GFS_F_PLAIN_LOADS   1u        /* read positions with plain (L2-cacheable) loads instead
+                                         of agent-scope relaxed atomic loads                 */
+#define GFS_F_NO_LDS_TABLES 2u        /* keep zeta/path tables in global memory              */
+
+typedef struct gfs_stats {
+    uint64_t term_updates;            /* successful updates, counted where sgd.rs:579 counts */
+    uint64_t attempts;                /* loop trips including `continue`s                    */
+    uint64_t iterations;              /* batches launched                                    */
+    uint64_t n_streams;               /* streams actually used                               */
+    double   kernel_ms;               /* sum of SGD kernel durations (HIP events)            */
+    double   total_ms;                /* wall time inside the call (one-shot) / run          */
+} gfs_stats;
+
+/* One sampled term (debug trace): 1D i,j = dense node index; nD = 2*idx+end. */
+typedef struct gfs_term {
+    uint32_t i, j;
+    double   d_ij;
+} gfs_term;
+
+typedef struct gfs_ctx gfs_ctx;
+
+/* ---- library ---- */
+const char *gfs_version(void);
+const char *gfs_last_error(void);
+int         gfs_device_count(void);
+
+/* ---- host tables, bit-exact restatements (no device needed) ---- */
+/* fast_precise_pow                                                        sgd.rs:155-182 */
+double   gfs_fast_precise_pow(double a, double b);
+/* path_linear_sgd_schedule with w_min=1/eta_max, w_max=1: etas[iter_max+1]  sgd.rs:300-308,617-638 */
+int      gfs_sgd_schedule(const gfs_sgd_params *p, double *etas);
+/* zeta table length and contents                                          sgd.rs:311-331 */
+uint64_t gfs_zeta_table_len(const gfs_sgd_params *p);
+int      gfs_zeta_table(const gfs_sgd_params *p, double *zetas);
+/* initial positions x[idx] = bp prefix in node_order                      sgd.rs:271-294 */
+int      gfs_init_positions(const gfs_graph_view *g, double *x);
+/* layout init, dimension 0 only (+end = prefix, -end = prefix+len), Layout order; the
+ * Gaussian dimensions >=1 (rand_distr StandardNormal, sgd.rs:829-850) are the caller's.    */
+int      gfs_init_layout_dim0(const gfs_graph_view *g, uint64_t dims, double *coords);
+/* positions -> rank order (ascending, ties by dense index)                sgd.rs:665-671 */
+int      gfs_sort_order(const double *x, uint64_t n, uint64_t *order);
+
+/* ---- one-shot entry points: what the Rust seam functions bind ---- */
+/* replaces path_linear_sgd (src/sgd.rs:237).  x_inout[n_nodes]: in = initial positions
+ * (NULL-initialised by gfs_init_positions if init_x != 0), out = final positions.
+ * etas / zetas may be NULL (computed as the reference does).                               */
+int gfs_path_linear_sgd(const gfs_graph_view *g, const gfs_sgd_params *p,
+                        const gfs_launch_config *cfg, const double *etas, const double *zetas,
+                        int init_x, double *x_inout, gfs_stats *stats);
+/* replaces path_linear_sgd_layout (src/sgd.rs:773).  coords_inout[n_nodes*2*D] in the order of
+ * Layout.coords: coords[node*2*D + end*D + dim] (src/layout.rs:14,73-78).                   */
+int gfs_path_linear_sgd_layout(const gfs_graph_view *g, const gfs_layout_params *p,
+                               const gfs_launch_config *cfg, const double *etas, const double *zetas,
+                               double *coords_inout, gfs_stats *stats);
+
+/* ---- resident API: graph and positions stay in HBM between calls ---- */
+int   gfs_ctx_create(const gfs_graph_view *g, int device, gfs_ctx **out);
+void  gfs_ctx_destroy(gfs_ctx *ctx);
+int   gfs_ctx_setup_1d(gfs_ctx *ctx, const gfs_sgd_params *p, const gfs_launch_config *cfg,
+                       const double *etas, const double *zetas);
+int   gfs_ctx_setup_nd(gfs_ctx *ctx, const gfs_layout_params *p, const gfs_launch_config *cfg,
+                       const double *etas, const double *zetas);
+uint64_t gfs_ctx_positions_len(const gfs_ctx *ctx);              /* n_nodes (1D) or n_nodes*2*D */
+int   gfs_ctx_upload_positions(gfs_ctx *ctx, const double *host, uint64_t n);
+int   gfs_ctx_download_positions(gfs_ctx *ctx, double *host, uint64_t n);
+void *gfs_ctx_positions_device(gfs_ctx *ctx);                    /* device pointer (for RCCL)   */
+int   gfs_ctx_bind_positions(gfs_ctx *ctx, void *device_ptr);    /* use a caller-owned buffer   */
+int   gfs_ctx_reset_streams(gfs_ctx *ctx);                       /* re-seed RNG streams, zero stats */
+/* one SGD batch: iteration k in 0..=iter_max uses etas[k]; cooling for
+ * k > floor(cooling_start*iter_max) (sgd.rs:297,383-396).  Asynchronous on hip_stream
+ * (a hipStream_t, NULL = the default stream).                                               */
+int   gfs_ctx_run_iteration(gfs_ctx *ctx, uint64_t k, void *hip_stream);
+int   gfs_ctx_run(gfs_ctx *ctx, void *hip_stream);               /* k = 0..=iter_max, then sync */
+int   gfs_ctx_synchronize(gfs_ctx *ctx, void *hip_stream);
+int   gfs_ctx_stats(gfs_ctx *ctx, gfs_stats *out);               /* synchronises                */
+int   gfs_ctx_trace(gfs_ctx *ctx, gfs_term *out, uint64_t n_terms, uint64_t *counts, uint64_t n_streams);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,728 @@
+/*
+ * gfs_oracle.c — CPU ORACLE (test infrastructure only; see gfs_oracle.h for the rules and
+ * the "parity unpinned" statement).  Plain C11 restatement of pangenome/gfasort src/sgd.rs.
+ * Every function cites the reference lines it follows as `sgd.rs:NNN`.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: Rust never contracts a*b+c into an
+ * fma, so neither may we; x86-64 SSE2 doubles are IEEE binary64 like Rust's f64).
+ */
+#define _GNU_SOURCE
+#include "gfs_oracle.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Rust `as` casts saturate and map NaN to 0 (used at sgd.rs:149,157,164).
+ * ---------------------------------------------------------------------------------------- */
+static inline int32_t sat_i32(double v) {
+    if (v != v) return 0;
+    if (v <= -2147483648.0) return INT32_MIN;
+    if (v >= 2147483647.0) return INT32_MAX;
+    return (int32_t)v;
+}
+static inline uint64_t sat_u64(double v) {
+    if (!(v > 0.0)) return 0;                       /* NaN, negatives, zeros */
+    if (v >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)v;
+}
+static inline double bits_f64(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+static inline uint64_t f64_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+static double now_s(void) {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * fast_precise_pow — sgd.rs:155-182.  Integer part of the exponent by square-and-multiply,
+ * fractional part by a linear map on the high 32 bits of the IEEE-754 word; the literal
+ * 1072632447 is authoritative (the source comment calling it 0x3FF00000 is wrong).
+ * `high - 1072632447` wraps like release-mode Rust i32 arithmetic.
+ * ---------------------------------------------------------------------------------------- */
+double gfo_fast_precise_pow(double a, double b) {
+    int32_t e = sat_i32(b);                                           /* :157 */
+    int32_t high = (int32_t)(f64_bits(a) >> 32);                      /* :162-163 */
+    int32_t diff = (int32_t)((uint32_t)high - 1072632447u);
+    int32_t new_high = sat_i32((b - (double)e) * (double)diff + 1072632447.0);  /* :164 */
+    double frac_result = bits_f64(((uint64_t)(uint32_t)new_high) << 32);        /* :166-167 */
+    double base = a, r = 1.0;
+    int32_t ex = e;
+    while (ex != 0) {                                                 /* :173-179 */
+        if (ex & 1) r *= base;
+        base *= base;
+        ex >>= 1;                 /* arithmetic shift, as Rust i32 >>; callers keep b >= 0 */
+    }
+    return r * frac_result;                                           /* :181 */
+}
+#define fpp gfo_fast_precise_pow
+
+/* ------------------------------------------------------------------------------------------
+ * DirtyZipfian::sample — sgd.rs:128-150, with the uniform draw `u` passed in.
+ * NB the second fast path returns min+1 without clamping to max (inherited).
+ * ---------------------------------------------------------------------------------------- */
+uint64_t gfo_dirty_zipfian(uint64_t min, uint64_t max, double theta,
+                           double zeta, double zeta2theta, double u) {
+    uint64_t n = max - min + 1;                                       /* :129 */
+    double alpha = 1.0 / (1.0 - theta);                               /* :132 */
+    double eta = (1.0 - fpp(2.0 / (double)n, 1.0 - theta))
+               / (1.0 - zeta2theta / zeta);                           /* :133-134 */
+    double uz = u * zeta;                                             /* :137 */
+    if (uz < 1.0) return min;                                         /* :140 */
+    if (uz < 1.0 + fpp(0.5, theta)) return min + 1;                   /* :143 */
+    double result = (double)min + ((double)n * fpp(eta * u - eta + 1.0, alpha));  /* :148 */
+    uint64_t r = sat_u64(result);
+    return r < max ? r : max;                                         /* :149 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * RNG — rand_xoshiro 0.7 Xoshiro256Plus, seeded by SplitMix64 (seed_from_u64), as used at
+ * sgd.rs:432,829,980,1218.  Third-party crate, source not in /root/reference: restated from
+ * the published generators (Blackman & Vigna).  UNPINNED by the reference.
+ * ---------------------------------------------------------------------------------------- */
+uint64_t gfo_splitmix64_next(uint64_t *state) {
+    uint64_t z = (*state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+void gfo_xoshiro_seed(uint64_t seed, uint64_t s[4]) {
+    uint64_t sm = seed;
+    for (int k = 0; k < 4; k++) s[k] = gfo_splitmix64_next(&sm);
+}
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline uint64_t xo_next(uint64_t s[4]) {
+    uint64_t result = s[0] + s[3];
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+uint64_t gfo_xoshiro_next(uint64_t s[4]) { return xo_next(s); }
+
+/* rand 0.9 `Uniform::new(0, n).sample()` for usize: u32 draws (next_u64 >> 32) when
+ * n <= u32::MAX, else u64 draws; widening multiply; accept iff lo >= (2^w - n) mod n. */
+static inline uint64_t uniform_usize(uint64_t s[4], uint64_t n) {
+    if (n <= 0xFFFFFFFFull) {
+        uint32_t range = (uint32_t)n;
+        uint32_t thresh = (uint32_t)(0u - range) % range;
+        for (;;) {
+            uint64_t m = (uint64_t)(uint32_t)(xo_next(s) >> 32) * (uint64_t)range;
+            if ((uint32_t)m >= thresh) return m >> 32;
+        }
+    } else {
+        uint64_t thresh = (0ull - n) % n;
+        for (;;) {
+            unsigned __int128 m = (unsigned __int128)xo_next(s) * n;
+            if ((uint64_t)m >= thresh) return (uint64_t)(m >> 64);
+        }
+    }
+}
+uint64_t gfo_uniform_usize(uint64_t s[4], uint64_t n) { return uniform_usize(s, n); }
+/* `Uniform::new(0, 2)` on default-i32: one u32 draw, wmul by 2, threshold 0 => top bit. */
+static inline uint32_t flip(uint64_t s[4]) { return (uint32_t)(xo_next(s) >> 63); }
+uint32_t gfo_flip(uint64_t s[4]) { return flip(s); }
+/* `rng.random::<f64>()`: 53 high bits * 2^-53 */
+static inline double random_f64(uint64_t s[4]) {
+    return (double)(xo_next(s) >> 11) * (1.0 / 9007199254740992.0);
+}
+double gfo_random_f64(uint64_t s[4]) { return random_f64(s); }
+
+/* ------------------------------------------------------------------------------------------
+ * path_linear_sgd_schedule — sgd.rs:617-638 (w_min = 1/eta_max, w_max = 1 at :300-301).
+ * ---------------------------------------------------------------------------------------- */
+void gfo_schedule(const gfo_params *p, double *etas) {
+    double w_min = 1.0 / p->eta_max, w_max = 1.0;
+    double eta_max = 1.0 / w_min;                                     /* :627 */
+    double eta_min = p->eps / w_max;                                  /* :628 */
+    double lambda = log(eta_max / eta_min) / ((double)p->iter_max - 1.0);  /* :629 */
+    for (uint64_t t = 0; t <= p->iter_max; t++) {                     /* :632 */
+        int64_t d = (int64_t)t - (int64_t)p->iter_with_max_learning_rate;
+        if (d < 0) d = -d;
+        etas[t] = eta_max * exp(-lambda * (double)d);                 /* :633 */
+    }
+}
+
+/* zeta table — sgd.rs:311-331 (identical copy at :871-890) */
+uint64_t gfo_zeta_size(const gfo_params *p) {
+    uint64_t n = (p->space <= p->space_max)
+        ? p->space
+        : p->space_max + (p->space - p->space_max) / p->space_quantization_step + 1;
+    return n + 1;
+}
+void gfo_zetas(const gfo_params *p, double *zetas) {
+    uint64_t len = gfo_zeta_size(p);
+    for (uint64_t k = 0; k < len; k++) zetas[k] = 0.0;
+    double zeta_tmp = 0.0;
+    for (uint64_t i = 1; i <= p->space; i++) {
+        zeta_tmp += fpp(1.0 / (double)i, p->theta);                   /* :321 */
+        if (i <= p->space_max) zetas[i] = zeta_tmp;
+        if (i >= p->space_max && (i - p->space_max) % p->space_quantization_step == 0) {
+            uint64_t idx = p->space_max + 1 + (i - p->space_max) / p->space_quantization_step;
+            if (idx < len) zetas[idx] = zeta_tmp;
+        }
+    }
+}
+
+/* PathIndex::from_graph — sgd.rs:34-71.  A step on a node absent from the graph adds 0 bp. */
+void gfo_path_index(const gfo_graph *g, uint64_t *step_pos, uint32_t *step_path,
+                    uint64_t *step_rank, uint64_t *path_len) {
+    for (uint64_t pth = 0; pth < g->n_paths; pth++) {
+        uint64_t position = 0;
+        uint64_t b = g->path_first_step[pth], e = g->path_first_step[pth + 1];
+        for (uint64_t s = b; s < e; s++) {
+            if (step_pos) step_pos[s] = position;
+            if (step_path) step_path[s] = (uint32_t)pth;
+            if (step_rank) step_rank[s] = s - b;
+            uint32_t n = g->step_node[s];
+            if (n != GFO_NO_NODE) position += g->node_len[n];
+        }
+        if (path_len) path_len[pth] = position;
+    }
+}
+
+void gfo_init_positions(const gfo_graph *g, double *x) {              /* sgd.rs:271-294 */
+    uint64_t len = 0;
+    for (uint64_t i = 0; i < g->n_nodes; i++) { x[i] = (double)len; len += g->node_len[i]; }
+}
+void gfo_init_layout_dim0(const gfo_graph *g, uint64_t D, double *c) {   /* sgd.rs:832-853 */
+    uint64_t len = 0;
+    for (uint64_t i = 0; i < g->n_nodes; i++) {
+        c[i * 2 * D + 0 * D + 0] = (double)len;
+        c[i * 2 * D + 1 * D + 0] = (double)(len + g->node_len[i]);
+        len += g->node_len[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Internal PathIndex in two representations.
+ *  reference-like: four 8-byte arrays + PathInfo + a hash map handle->idx (sgd.rs:14-31,272)
+ *  flat          : 16-byte step records + 16-byte path records, dense idx stored in the step
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint64_t step_count, length, first_step; } path_info;
+typedef struct { uint32_t node; uint32_t path_rev; uint64_t pos; } step_rec;   /* flat */
+typedef struct { uint64_t key; uint64_t val; } hslot;
+
+typedef struct pidx {
+    uint64_t n_steps, n_paths, n_nodes;
+    /* reference-like */
+    uint64_t *step_to_handle, *step_to_position, *step_to_path, *step_to_rank;
+    path_info *paths;
+    hslot *hmap; uint64_t hmask;          /* Handle::forward(node_id) -> idx */
+    uint64_t *node_seq_len;               /* graph.nodes[id].sequence.len() by "node id" */
+    /* flat */
+    step_rec *rec;
+    const uint32_t *node_len;
+} pidx;
+
+static inline uint64_t hmix(uint64_t k) {  /* stand-in for SipHash: any decent 64-bit mixer */
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+static inline int64_t hmap_get(const pidx *pi, uint64_t key) {
+    uint64_t h = hmix(key) & pi->hmask;
+    for (;;) {
+        if (pi->hmap[h].key == key) return (int64_t)pi->hmap[h].val;
+        if (pi->hmap[h].key == UINT64_MAX) return -1;
+        h = (h + 1) & pi->hmask;
+    }
+}
+
+static void pidx_free(pidx *pi) {
+    free(pi->step_to_handle); free(pi->step_to_position); free(pi->step_to_path);
+    free(pi->step_to_rank); free(pi->paths); free(pi->hmap); free(pi->node_seq_len); free(pi->rec);
+    memset(pi, 0, sizeof *pi);
+}
+
+/* In the reference-like form the "node id" of dense idx k is k+1 (ids are only labels here;
+ * what matters is that the lookup goes handle -> hash map -> idx as at sgd.rs:525-538). */
+static int pidx_build(const gfo_graph *g, int flat, pidx *pi) {
+    memset(pi, 0, sizeof *pi);
+    pi->n_steps = g->n_steps; pi->n_paths = g->n_paths; pi->n_nodes = g->n_nodes;
+    pi->node_len = g->node_len;
+    uint64_t S = g->n_steps, P = g->n_paths;
+    pi->paths = (path_info *)calloc(P ? P : 1, sizeof(path_info));
+    uint64_t *pos = (uint64_t *)malloc((S ? S : 1) * 8);
+    uint32_t *pth = (uint32_t *)malloc((S ? S : 1) * 4);
+    uint64_t *plen = (uint64_t *)malloc((P ? P : 1) * 8);
+    if (!pi->paths || !pos || !pth || !plen) return -1;
+    gfo_path_index(g, pos, pth, NULL, plen);
+    for (uint64_t p = 0; p < P; p++) {
+        pi->paths[p].first_step = g->path_first_step[p];
+        pi->paths[p].step_count = g->path_first_step[p + 1] - g->path_first_step[p];
+        pi->paths[p].length = plen[p];
+    }
+    if (flat) {
+        pi->rec = (step_rec *)malloc((S ? S : 1) * sizeof(step_rec));
+        if (!pi->rec) return -1;
+        for (uint64_t s = 0; s < S; s++) {
+            pi->rec[s].node = g->step_node[s];
+            pi->rec[s].path_rev = pth[s] | ((uint32_t)(g->step_is_rev[s] & 1) << 31);
+            pi->rec[s].pos = pos[s];
+        }
+    } else {
+        pi->step_to_handle = (uint64_t *)malloc((S ? S : 1) * 8);
+        pi->step_to_position = pos; pos = NULL;
+        pi->step_to_path = (uint64_t *)malloc((S ? S : 1) * 8);
+        pi->step_to_rank = (uint64_t *)malloc((S ? S : 1) * 8);
+        uint64_t cap = 16; while (cap < 2 * g->n_nodes + 2) cap <<= 1;
+        pi->hmap = (hslot *)malloc(cap * sizeof(hslot)); pi->hmask = cap - 1;
+        pi->node_seq_len = (uint64_t *)calloc(g->n_nodes + 2, 8);
+        if (!pi->step_to_handle || !pi->step_to_path || !pi->step_to_rank || !pi->hmap || !pi->node_seq_len) return -1;
+        for (uint64_t k = 0; k < cap; k++) pi->hmap[k].key = UINT64_MAX;
+        for (uint64_t k = 0; k < g->n_nodes; k++) {
+            uint64_t key = (k + 1) << 1;            /* Handle::forward(id) = id<<1 (graph.rs:13-23) */
+            uint64_t h = hmix(key) & pi->hmask;
+            while (pi->hmap[h].key != UINT64_MAX) h = (h + 1) & pi->hmask;
+            pi->hmap[h].key = key; pi->hmap[h].val = k;
+            pi->node_seq_len[k + 1] = g->node_len[k];
+        }
+        for (uint64_t s = 0; s < S; s++) {
+            uint32_t n = g->step_node[s];
+            uint64_t id = (n == GFO_NO_NODE) ? (g->n_nodes + 1) : ((uint64_t)n + 1);  /* absent id */
+            pi->step_to_handle[s] = (id << 1) | (g->step_is_rev[s] & 1);
+            pi->step_to_path[s] = pth[s];
+            pi->step_to_rank[s] = s - g->path_first_step[pth[s]];
+        }
+    }
+    free(pos); free(pth); free(plen);
+    return 0;
+}
+
+/* per-iteration shared state (the reference's atomics eta / adj_theta / cooling) */
+typedef struct iter_state {
+    double eta, theta;
+    int cooling;
+} iter_state;
+
+typedef struct zipf_env {
+    const double *zetas; uint64_t zlen;
+    uint64_t space, space_max, q;
+} zipf_env;
+
+/* zeta index rule — sgd.rs:463-469 */
+static inline uint64_t space_index(const zipf_env *z, uint64_t jump_space) {
+    uint64_t idx = (jump_space > z->space_max)
+        ? z->space_max + (jump_space - z->space_max) / z->q + 1
+        : jump_space;
+    return idx < z->zlen - 1 ? idx : z->zlen - 1;
+}
+
+/* One trip of the sampler, sgd.rs:444-499 (1D) == :990-1037 (nD): draws step a, decides
+ * Zipf/uniform, draws rank b.  Returns 0 on `continue`, 1 with *sa,*sb = global step indices. */
+static inline __attribute__((always_inline)) int
+sample_pair(const pidx *pi, const int flat, const zipf_env *z, const iter_state *it,
+            uint64_t rng[4], uint64_t *sa, uint64_t *sb) {
+    uint64_t step_idx = uniform_usize(rng, pi->n_steps);              /* :444 */
+    uint64_t path_idx, rank_a;
+    if (flat) { path_idx = pi->rec[step_idx].path_rev & 0x7FFFFFFFu; }
+    else      { path_idx = pi->step_to_path[step_idx]; }              /* :445 */
+    uint64_t cnt = pi->paths[path_idx].step_count;                    /* :446 */
+    if (cnt == 1) return 0;                                           /* :448 */
+    if (flat) rank_a = step_idx - pi->paths[path_idx].first_step;
+    else      rank_a = pi->step_to_rank[step_idx];                    /* :452 */
+    uint64_t rank_b = rank_a;
+    if (it->cooling || flip(rng) == 1) {                              /* :456 short-circuit */
+        double theta = it->theta;                                     /* :458 */
+        if (rank_a > 0 && (flip(rng) == 1 || rank_a == cnt - 1)) {    /* :460 */
+            uint64_t jump = z->space < rank_a ? z->space : rank_a;    /* :462 */
+            uint64_t si = space_index(z, jump);
+            double zeta2theta = 1.0 + fpp(0.5, theta);                /* :471 */
+            uint64_t zi = gfo_dirty_zipfian(1, jump, theta, z->zetas[si], zeta2theta, random_f64(rng));
+            rank_b = rank_a >= zi ? rank_a - zi : 0;                  /* :474 saturating_sub */
+        } else if (rank_a < cnt - 1) {                                /* :475 */
+            uint64_t rem = cnt - rank_a - 1;
+            uint64_t jump = z->space < rem ? z->space : rem;          /* :477 */
+            uint64_t si = space_index(z, jump);
+            double zeta2theta = 1.0 + fpp(0.5, theta);                /* :486 */
+            uint64_t zi = gfo_dirty_zipfian(1, jump, theta, z->zetas[si], zeta2theta, random_f64(rng));
+            uint64_t rb = rank_a + zi;
+            rank_b = rb < cnt - 1 ? rb : cnt - 1;                     /* :489 */
+        }
+    } else {
+        rank_b = uniform_usize(rng, cnt);                             /* :493-494 */
+    }
+    if (rank_a == rank_b) return 0;                                   /* :497 */
+    *sa = pi->paths[path_idx].first_step + rank_a;                    /* :502 */
+    *sb = pi->paths[path_idx].first_step + rank_b;                    /* :503 */
+    return 1;
+}
+
+/* 1D term — sgd.rs:505-576.  xa/xb are the position slots; `atomic`: relaxed atomics like the
+ * reference's AtomicU64 (threaded mode) or plain doubles (deterministic mode). */
+static inline __attribute__((always_inline)) int
+term_1d(const pidx *pi, const int flat, const iter_state *it, uint64_t sa, uint64_t sb,
+        double *x, const int atomic, _Atomic uint64_t *delta_max, gfo_term *tr) {
+    double pos_a, pos_b; uint64_t i, j;
+    if (flat) {
+        pos_a = (double)pi->rec[sa].pos; pos_b = (double)pi->rec[sb].pos;
+    } else {
+        pos_a = (double)pi->step_to_position[sa]; pos_b = (double)pi->step_to_position[sb];  /* :509-510 */
+    }
+    double term_dist = fabs(pos_a - pos_b);                           /* :513 */
+    if (term_dist == 0.0) return 0;                                   /* :514 */
+    double term_weight = 1.0 / term_dist;                             /* :518 */
+    double mu = it->eta * term_weight;                                /* :519 */
+    mu = fmin(mu, 1.0);                                               /* :520 f64::min ignores a NaN operand, like fmin */
+    if (flat) {
+        uint32_t ni = pi->rec[sa].node, nj = pi->rec[sb].node;
+        if (ni == GFO_NO_NODE || nj == GFO_NO_NODE) return 0;
+        i = ni; j = nj;
+    } else {
+        int64_t li = hmap_get(pi, pi->step_to_handle[sa] & ~1ull);    /* :525 forward handle */
+        if (li < 0) return 0;
+        int64_t lj = hmap_get(pi, pi->step_to_handle[sb] & ~1ull);    /* :532 */
+        if (lj < 0) return 0;
+        i = (uint64_t)li; j = (uint64_t)lj;
+    }
+    _Atomic uint64_t *ax = (_Atomic uint64_t *)x;
+    double x_i, x_j;
+    if (atomic) {
+        x_i = bits_f64(atomic_load_explicit(&ax[i], memory_order_relaxed));
+        x_j = bits_f64(atomic_load_explicit(&ax[j], memory_order_relaxed));
+    } else { x_i = x[i]; x_j = x[j]; }                                /* :541-542 */
+    double dx = x_i - x_j;                                            /* :543 */
+    if (dx == 0.0) dx = 1e-9;                                         /* :546-548 */
+    double mag = fabs(dx);                                            /* :551 */
+    double delta_update = mu * (mag - term_dist) / 2.0;               /* :552 */
+    if (delta_max) {                                                  /* :555-567 dead value, kept for cost parity */
+        double delta_abs = fabs(delta_update);
+        uint64_t cur = atomic_load_explicit(delta_max, memory_order_relaxed);
+        while (delta_abs > bits_f64(cur)) {
+            if (atomic_compare_exchange_weak_explicit(delta_max, &cur, f64_bits(delta_abs),
+                                                      memory_order_relaxed, memory_order_relaxed)) break;
+        }
+    }
+    double r = delta_update / mag;                                    /* :570 */
+    double r_x = r * dx;                                              /* :571 */
+    if (atomic) {                                                     /* :575-576 load then store, racy by design */
+        double vi = bits_f64(atomic_load_explicit(&ax[i], memory_order_relaxed));
+        atomic_store_explicit(&ax[i], f64_bits(vi - r_x), memory_order_relaxed);
+        double vj = bits_f64(atomic_load_explicit(&ax[j], memory_order_relaxed));
+        atomic_store_explicit(&ax[j], f64_bits(vj + r_x), memory_order_relaxed);
+    } else {
+        x[i] = x[i] - r_x;
+        x[j] = x[j] + r_x;
+    }
+    if (tr) { tr->i = (uint32_t)i; tr->j = (uint32_t)j; tr->d_ij = term_dist; }
+    return 1;
+}
+
+/* nD term — sgd.rs:1043-1149.  coords in Layout order [node][end][dim]. */
+#define GFO_MAX_DIMS 16
+static inline __attribute__((always_inline)) int
+term_nd(const pidx *pi, const int flat, const iter_state *it, uint64_t rng[4], uint64_t sa, uint64_t sb,
+        double *c, const uint64_t D, const int atomic, _Atomic uint64_t *delta_max, gfo_term *tr) {
+    double pos_a, pos_b, len_i, len_j; int rev_i, rev_j; int64_t li, lj;
+    if (flat) {
+        pos_a = (double)pi->rec[sa].pos; pos_b = (double)pi->rec[sb].pos;
+        uint32_t ni = pi->rec[sa].node, nj = pi->rec[sb].node;
+        len_i = ni == GFO_NO_NODE ? 0.0 : (double)pi->node_len[ni];
+        len_j = nj == GFO_NO_NODE ? 0.0 : (double)pi->node_len[nj];
+        rev_i = (int)(pi->rec[sa].path_rev >> 31); rev_j = (int)(pi->rec[sb].path_rev >> 31);
+        li = ni == GFO_NO_NODE ? -1 : (int64_t)ni; lj = nj == GFO_NO_NODE ? -1 : (int64_t)nj;
+    } else {
+        uint64_t hi = pi->step_to_handle[sa], hj = pi->step_to_handle[sb];      /* :1043-1044 */
+        pos_a = (double)pi->step_to_position[sa]; pos_b = (double)pi->step_to_position[sb];
+        len_i = (double)pi->node_seq_len[hi >> 1];                   /* :1051-1058 (0 when absent) */
+        len_j = (double)pi->node_seq_len[hj >> 1];
+        rev_i = (int)(hi & 1); rev_j = (int)(hj & 1);
+        li = lj = -2;
+    }
+    int use_other_end_a = flip(rng) == 1;                             /* :1062 */
+    if (use_other_end_a) { pos_a += len_i; use_other_end_a = !rev_i; }
+    else                 { use_other_end_a = rev_i; }                 /* :1063-1068 */
+    int use_other_end_b = flip(rng) == 1;                             /* :1071 */
+    if (use_other_end_b) { pos_b += len_j; use_other_end_b = !rev_j; }
+    else                 { use_other_end_b = rev_j; }
+    double term_dist = fabs(pos_a - pos_b);                           /* :1080 */
+    if (term_dist == 0.0) return 0;
+    double mu = fmin(it->eta * (1.0 / term_dist), 1.0);               /* :1085-1086 */
+    if (!flat) {
+        li = hmap_get(pi, pi->step_to_handle[sa] & ~1ull);            /* :1089 */
+        if (li < 0) return 0;
+        lj = hmap_get(pi, pi->step_to_handle[sb] & ~1ull);
+        if (lj < 0) return 0;
+    } else if (li < 0 || lj < 0) return 0;
+    uint64_t idx_i = (uint64_t)li * 2 + (use_other_end_a ? 1 : 0);    /* :1099-1103 */
+    uint64_t idx_j = (uint64_t)lj * 2 + (use_other_end_b ? 1 : 0);
+    double *ci = c + idx_i * D, *cj = c + idx_j * D;
+    _Atomic uint64_t *ai = (_Atomic uint64_t *)ci, *aj = (_Atomic uint64_t *)cj;
+    double deltas[GFO_MAX_DIMS];
+    double mag_sq = 0.0;
+    for (uint64_t d = 0; d < D; d++) {                                /* :1108-1113 */
+        double vi = atomic ? bits_f64(atomic_load_explicit(&ai[d], memory_order_relaxed)) : ci[d];
+        double vj = atomic ? bits_f64(atomic_load_explicit(&aj[d], memory_order_relaxed)) : cj[d];
+        deltas[d] = vi - vj;
+        mag_sq += deltas[d] * deltas[d];
+    }
+    if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }         /* :1116-1119 */
+    double mag = sqrt(mag_sq);                                        /* :1121 */
+    double delta_update = mu * (mag - term_dist) / 2.0;               /* :1125 */
+    if (delta_max) {
+        double delta_abs = fabs(delta_update);
+        uint64_t cur = atomic_load_explicit(delta_max, memory_order_relaxed);
+        while (delta_abs > bits_f64(cur)) {
+            if (atomic_compare_exchange_weak_explicit(delta_max, &cur, f64_bits(delta_abs),
+                                                      memory_order_relaxed, memory_order_relaxed)) break;
+        }
+    }
+    double r = delta_update / mag;                                    /* :1142 */
+    for (uint64_t d = 0; d < D; d++) {                                /* :1143-1149 */
+        double r_d = r * deltas[d];
+        if (atomic) {
+            double vi = bits_f64(atomic_load_explicit(&ai[d], memory_order_relaxed));
+            double vj = bits_f64(atomic_load_explicit(&aj[d], memory_order_relaxed));
+            atomic_store_explicit(&ai[d], f64_bits(vi - r_d), memory_order_relaxed);
+            atomic_store_explicit(&aj[d], f64_bits(vj + r_d), memory_order_relaxed);
+        } else {
+            double vi = ci[d], vj = cj[d];       /* both loaded before either store (matters when idx_i==idx_j) */
+            ci[d] = vi - r_d;
+            cj[d] = vj + r_d;
+        }
+    }
+    if (tr) { tr->i = (uint32_t)idx_i; tr->j = (uint32_t)idx_j; tr->d_ij = term_dist; }
+    return 1;
+}
+
+/* iteration constants: batch k uses etas[k]; cooling for k > floor(cooling_start*iter_max)
+ * (sgd.rs:297, 383-396): eta/theta/cooling are switched when the checker moves to new_iter=k. */
+static void iter_consts(const gfo_params *p, const double *etas, uint64_t k, iter_state *it) {
+    uint64_t first_cooling = sat_u64(floor(p->cooling_start * (double)p->iter_max));
+    it->eta = etas[k];
+    it->cooling = (k > first_cooling);
+    it->theta = it->cooling ? 0.001 : p->theta;
+}
+
+static int has_valid_paths(const gfo_graph *g) {                      /* sgd.rs:250-261 */
+    for (uint64_t p = 0; p < g->n_paths; p++)
+        if (g->path_first_step[p + 1] - g->path_first_step[p] > 1) return 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Deterministic mode.
+ * ---------------------------------------------------------------------------------------- */
+static int sgd_det(const gfo_graph *g, const gfo_params *p, const double *etas_in, const double *zetas_in,
+                   uint64_t T, uint64_t attempt_factor, double *x, uint64_t D /*0 = 1D*/,
+                   gfo_term *trace, uint64_t trace_per_stream, gfo_stats *st) {
+    if (st) memset(st, 0, sizeof *st);
+    if (g->n_nodes == 0 || !has_valid_paths(g)) return 1;             /* sgd.rs:242-244, 258-261 */
+    if (T == 0 || D > GFO_MAX_DIMS) return -1;
+    pidx pi;
+    if (pidx_build(g, 1, &pi)) { pidx_free(&pi); return -2; }
+    double *etas = NULL, *zetas = NULL;
+    if (!etas_in) { etas = (double *)malloc((p->iter_max + 1) * 8); gfo_schedule(p, etas); etas_in = etas; }
+    if (!zetas_in) { zetas = (double *)malloc(gfo_zeta_size(p) * 8); gfo_zetas(p, zetas); zetas_in = zetas; }
+    zipf_env z = { zetas_in, gfo_zeta_size(p), p->space, p->space_max, p->space_quantization_step };
+    uint64_t *rng = (uint64_t *)malloc(T * 32);
+    uint64_t *done = (uint64_t *)malloc(T * 8), *att = (uint64_t *)malloc(T * 8), *ntr = (uint64_t *)calloc(T, 8);
+    for (uint64_t t = 0; t < T; t++) gfo_xoshiro_seed(p->seed + t, rng + 4 * t);   /* sgd.rs:431-432 */
+    uint64_t base = p->min_term_updates / T, rem = p->min_term_updates % T;
+    uint64_t total_upd = 0, total_att = 0;
+    double t0 = now_s();
+    for (uint64_t k = 0; k <= p->iter_max; k++) {
+        iter_state it; iter_consts(p, etas_in, k, &it);
+        memset(done, 0, T * 8); memset(att, 0, T * 8);
+        for (;;) {
+            int active = 0;
+            for (uint64_t t = 0; t < T; t++) {
+                uint64_t quota = base + (t < rem ? 1 : 0);
+                if (done[t] >= quota || att[t] >= attempt_factor * quota + 1024) continue;
+                active = 1;
+                att[t]++;
+                uint64_t sa, sb;
+                if (!sample_pair(&pi, 1, &z, &it, rng + 4 * t, &sa, &sb)) continue;
+                gfo_term tr;
+                int ok = D ? term_nd(&pi, 1, &it, rng + 4 * t, sa, sb, x, D, 0, NULL, &tr)
+                           : term_1d(&pi, 1, &it, sa, sb, x, 0, NULL, &tr);
+                if (!ok) continue;
+                done[t]++;
+                if (trace && ntr[t] < trace_per_stream) trace[t * trace_per_stream + ntr[t]++] = tr;
+            }
+            if (!active) break;
+        }
+        for (uint64_t t = 0; t < T; t++) { total_upd += done[t]; total_att += att[t]; }
+    }
+    if (st) { st->term_updates = total_upd; st->attempts = total_att; st->iterations = p->iter_max + 1; st->seconds = now_s() - t0; }
+    free(rng); free(done); free(att); free(ntr); free(etas); free(zetas);
+    pidx_free(&pi);
+    return 0;
+}
+
+int gfo_sgd_1d(const gfo_graph *g, const gfo_params *p, const double *etas, const double *zetas,
+               uint64_t n_streams, uint64_t attempt_factor, double *x,
+               gfo_term *trace, uint64_t trace_per_stream, gfo_stats *st) {
+    return sgd_det(g, p, etas, zetas, n_streams, attempt_factor, x, 0, trace, trace_per_stream, st);
+}
+int gfo_sgd_nd(const gfo_graph *g, const gfo_params *p, const double *etas, const double *zetas,
+               uint64_t n_streams, uint64_t attempt_factor, double *coords,
+               gfo_term *trace, uint64_t trace_per_stream, gfo_stats *st) {
+    if (p->dimensions == 0) return -1;
+    return sgd_det(g, p, etas, zetas, n_streams, attempt_factor, coords, p->dimensions, trace, trace_per_stream, st);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Reference-like threaded mode: Hogwild workers + 1 ms checker (sgd.rs:340-407, 413-601).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct shared {
+    const pidx *pi; int flat; const gfo_params *p; const double *etas; zipf_env z;
+    double *x; uint64_t D;
+    _Atomic uint64_t term_updates, iteration, eta_bits, theta_bits, delta_max, total_updates, total_attempts;
+    _Atomic int cooling, work_todo;
+    double deadline;
+} shared;
+typedef struct wargs { shared *sh; uint64_t tid; } wargs;
+
+static void *checker_main(void *arg) {                                /* sgd.rs:366-407 */
+    shared *sh = (shared *)arg;
+    const gfo_params *p = sh->p;
+    uint64_t first_cooling = sat_u64(floor(p->cooling_start * (double)p->iter_max));
+    while (atomic_load_explicit(&sh->work_todo, memory_order_relaxed)) {
+        uint64_t cur = atomic_load_explicit(&sh->term_updates, memory_order_relaxed);
+        if (cur >= p->min_term_updates) {
+            uint64_t new_iter = atomic_fetch_add_explicit(&sh->iteration, 1, memory_order_relaxed) + 1;
+            if (new_iter > p->iter_max) {
+                atomic_store_explicit(&sh->work_todo, 0, memory_order_relaxed);
+            } else {
+                atomic_store_explicit(&sh->eta_bits, f64_bits(sh->etas[new_iter]), memory_order_relaxed);
+                if (new_iter > first_cooling) {
+                    atomic_store_explicit(&sh->theta_bits, f64_bits(0.001), memory_order_relaxed);
+                    atomic_store_explicit(&sh->cooling, 1, memory_order_relaxed);
+                }
+            }
+            atomic_fetch_add_explicit(&sh->total_updates, cur, memory_order_relaxed);
+            atomic_store_explicit(&sh->term_updates, 0, memory_order_relaxed);   /* :400 */
+        }
+        if (sh->deadline > 0.0 && now_s() > sh->deadline)
+            atomic_store_explicit(&sh->work_todo, 0, memory_order_relaxed);       /* bounded sample */
+        struct timespec ts = { 0, 1000000 }; nanosleep(&ts, NULL);               /* :403 */
+    }
+    return NULL;
+}
+
+static void *worker_main(void *arg) {                                 /* sgd.rs:429-590 */
+    wargs *wa = (wargs *)arg; shared *sh = wa->sh;
+    uint64_t rng[4]; gfo_xoshiro_seed(sh->p->seed + wa->tid, rng);
+    uint64_t local = 0, attempts = 0;
+    const int flat = sh->flat;
+    while (atomic_load_explicit(&sh->work_todo, memory_order_relaxed)) {
+        attempts++;
+        iter_state it;
+        it.cooling = atomic_load_explicit(&sh->cooling, memory_order_relaxed);
+        it.theta = bits_f64(atomic_load_explicit(&sh->theta_bits, memory_order_relaxed));
+        it.eta = bits_f64(atomic_load_explicit(&sh->eta_bits, memory_order_relaxed));
+        uint64_t sa, sb; int ok;
+        if (flat) {
+            if (!sample_pair(sh->pi, 1, &sh->z, &it, rng, &sa, &sb)) continue;
+            ok = sh->D ? term_nd(sh->pi, 1, &it, rng, sa, sb, sh->x, sh->D, 1, NULL, NULL)
+                       : term_1d(sh->pi, 1, &it, sa, sb, sh->x, 1, NULL, NULL);
+        } else {
+            if (!sample_pair(sh->pi, 0, &sh->z, &it, rng, &sa, &sb)) continue;
+            ok = sh->D ? term_nd(sh->pi, 0, &it, rng, sa, sb, sh->x, sh->D, 1, &sh->delta_max, NULL)
+                       : term_1d(sh->pi, 0, &it, sa, sb, sh->x, 1, &sh->delta_max, NULL);
+        }
+        if (!ok) continue;
+        if (++local >= 1000) {                                        /* :579-583 */
+            atomic_fetch_add_explicit(&sh->term_updates, local, memory_order_relaxed);
+            local = 0;
+        }
+    }
+    if (local) atomic_fetch_add_explicit(&sh->term_updates, local, memory_order_relaxed);
+    atomic_fetch_add_explicit(&sh->total_attempts, attempts, memory_order_relaxed);
+    return NULL;
+}
+
+static int sgd_threads(const gfo_graph *g, const gfo_params *p, const double *etas_in, const double *zetas_in,
+                       int flat, double max_seconds, double *x, uint64_t D, gfo_stats *st) {
+    if (st) memset(st, 0, sizeof *st);
+    if (g->n_nodes == 0 || !has_valid_paths(g)) return 1;
+    if (D > GFO_MAX_DIMS) return -1;
+    pidx pi;
+    if (pidx_build(g, flat, &pi)) { pidx_free(&pi); return -2; }
+    double *etas = NULL, *zetas = NULL;
+    if (!etas_in) { etas = (double *)malloc((p->iter_max + 1) * 8); gfo_schedule(p, etas); etas_in = etas; }
+    if (!zetas_in) { zetas = (double *)malloc(gfo_zeta_size(p) * 8); gfo_zetas(p, zetas); zetas_in = zetas; }
+    shared sh; memset(&sh, 0, sizeof sh);
+    sh.pi = &pi; sh.flat = flat; sh.p = p; sh.etas = etas_in; sh.x = x; sh.D = D;
+    sh.z = (zipf_env){ zetas_in, gfo_zeta_size(p), p->space, p->space_max, p->space_quantization_step };
+    atomic_store(&sh.eta_bits, f64_bits(etas_in[0]));
+    atomic_store(&sh.theta_bits, f64_bits(p->theta));
+    atomic_store(&sh.work_todo, 1);
+    double t0 = now_s();
+    sh.deadline = max_seconds > 0.0 ? t0 + max_seconds : 0.0;
+    uint64_t T = p->nthreads;
+    pthread_t chk; pthread_t *th = (pthread_t *)malloc((T ? T : 1) * sizeof(pthread_t));
+    wargs *wa = (wargs *)malloc((T ? T : 1) * sizeof(wargs));
+    pthread_create(&chk, NULL, checker_main, &sh);
+    for (uint64_t t = 0; t < T; t++) { wa[t].sh = &sh; wa[t].tid = t; pthread_create(&th[t], NULL, worker_main, &wa[t]); }
+    if (T == 0) atomic_store(&sh.work_todo, 0);      /* no workers: reference would spin forever; stop */
+    for (uint64_t t = 0; t < T; t++) pthread_join(th[t], NULL);
+    atomic_store(&sh.work_todo, 0);
+    pthread_join(chk, NULL);
+    double t1 = now_s();
+    if (st) {
+        st->term_updates = atomic_load(&sh.total_updates) + atomic_load(&sh.term_updates);
+        st->attempts = atomic_load(&sh.total_attempts);
+        st->iterations = atomic_load(&sh.iteration);
+        st->seconds = t1 - t0;
+    }
+    free(th); free(wa); free(etas); free(zetas);
+    pidx_free(&pi);
+    return 0;
+}
+int gfo_sgd_1d_threads(const gfo_graph *g, const gfo_params *p, const double *etas, const double *zetas,
+                       int flat, double max_seconds, double *x, gfo_stats *st) {
+    return sgd_threads(g, p, etas, zetas, flat, max_seconds, x, 0, st);
+}
+int gfo_sgd_nd_threads(const gfo_graph *g, const gfo_params *p, const double *etas, const double *zetas,
+                       int flat, double max_seconds, double *coords, gfo_stats *st) {
+    if (p->dimensions == 0) return -1;
+    return sgd_threads(g, p, etas, zetas, flat, max_seconds, coords, p->dimensions, st);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * calculate_layout_stress — sgd.rs:1196-1283 (+ end of both nodes, seed 12345).
+ * ---------------------------------------------------------------------------------------- */
+static double stress_impl(const gfo_graph *g, uint64_t D, uint64_t stride, const double *c, uint64_t samples) {
+    if (g->n_steps < 2) return 0.0;                                   /* :1220 */
+    uint64_t *pos = (uint64_t *)malloc(g->n_steps * 8);
+    uint32_t *pth = (uint32_t *)malloc(g->n_steps * 4);
+    gfo_path_index(g, pos, pth, NULL, NULL);
+    uint64_t rng[4]; gfo_xoshiro_seed(12345, rng);                    /* :1218 */
+    double stress_sum = 0.0; uint64_t count = 0;
+    for (uint64_t k = 0; k < samples; k++) {
+        uint64_t step_a = uniform_usize(rng, g->n_steps);             /* :1230 */
+        uint64_t p = pth[step_a];
+        uint64_t first = g->path_first_step[p], cnt = g->path_first_step[p + 1] - first;
+        if (cnt < 2) continue;
+        uint64_t rank_a = step_a - first;
+        uint64_t rank_b = uniform_usize(rng, cnt);                    /* :1239-1240 */
+        if (rank_a == rank_b) continue;
+        uint64_t sa = first + rank_a, sb = first + rank_b;
+        double path_dist = fabs((double)pos[sa] - (double)pos[sb]);   /* :1252-1254 */
+        if (path_dist == 0.0) continue;
+        uint32_t ia = g->step_node[sa], ib = g->step_node[sb];
+        if (ia == GFO_NO_NODE || ib == GFO_NO_NODE) continue;
+        double sum_sq = 0.0;                                          /* layout.rs:126-133 */
+        for (uint64_t d = 0; d < D; d++) {
+            double delta = c[(uint64_t)ia * stride + d] - c[(uint64_t)ib * stride + d];
+            sum_sq += delta * delta;
+        }
+        double err = sqrt(sum_sq) - path_dist;                        /* :1273 */
+        stress_sum += (err * err) / (path_dist * path_dist);          /* :1274 */
+        count++;
+    }
+    free(pos); free(pth);
+    return count ? sqrt(stress_sum / (double)count) : 0.0;            /* :1278-1282 */
+}
+double gfo_layout_stress(const gfo_graph *g, uint64_t dims, const double *coords, uint64_t sample_count) {
+    return stress_impl(g, dims, 2 * dims, coords, sample_count);
+}
+double gfo_stress_1d(const gfo_graph *g, const double *x, uint64_t sample_count) {
+    return stress_impl(g, 1, 1, x, sample_count);
+}
