@@ -464,6 +464,7 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     a.space = (uint32_t)std::min<uint64_t>(c->params.space, 0xFFFFFFFFull);
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
+    a.dbg = (c->cfg.flags >> 8) & 0xFFu;
     iter_consts(c, k, a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
     if (c->events_used == c->events.size()) {

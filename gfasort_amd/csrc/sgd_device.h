@@ -95,7 +95,7 @@ struct KArgs {
     uint32_t quota_base, quota_rem;
     uint32_t attempt_factor, trace_per_stream;
     uint32_t space, space_max, space_q;
-    uint32_t _pad;
+    uint32_t dbg;                  // diagnostic ablation bits (GFS_F_DBG_* >> 8), 0 in production
     IterConsts it;
 };
 

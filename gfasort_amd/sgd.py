@@ -1,0 +1,77 @@
+"""Host-side mirror of the reference's SGD entry points, running on the HIP engine.
+
+Reference call chain (src/ygs.rs:195-206 -> src/sgd.rs:641-672 -> src/sgd.rs:237-614):
+    sgd_sort_only -> path_sgd_sort -> path_linear_sgd
+and the layout arm (src/bin/gfasort.rs:265-274 -> src/sgd.rs:773-1188).
+Same names, argument meaning and empty-result behaviour; positions are indexed by the dense
+node index (position in node_order) exactly like the reference's HashMap<usize,f64> keys.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import hip
+from .graph import FlatGraph
+from .layout import Layout
+from .params import LayoutSGDParams, PathSGDParams
+
+
+def path_linear_sgd(graph: FlatGraph, params: PathSGDParams, cfg=None,
+                    return_stats: bool = False):
+    """sgd.rs:237.  Returns float64[n_nodes] positions, or an EMPTY array when the reference
+    returns an empty map (no nodes / no path with more than one step, sgd.rs:242-244,258-261)."""
+    if graph.n_nodes == 0:
+        return (np.zeros(0), None) if return_stats else np.zeros(0)
+    rc, x, st = hip.path_linear_sgd_raw(graph, params, cfg=cfg)
+    if rc == hip.NOTHING_TO_DO:
+        x = np.zeros(0)
+    return (x, st) if return_stats else x
+
+
+def path_sgd_sort(graph: FlatGraph, params: PathSGDParams, cfg=None) -> np.ndarray:
+    """sgd.rs:641-672: dense node indices in ascending position order.  (The reference breaks
+    ties by HashMap iteration order, i.e. randomly; here ties keep node_order.)"""
+    x = path_linear_sgd(graph, params, cfg)
+    if x.shape[0] == 0:
+        return np.zeros(0, dtype=np.uint64)
+    return hip.sort_order(x)
+
+
+def sgd_sort_only(graph: FlatGraph, params: PathSGDParams, verbose: int = 0, cfg=None) -> np.ndarray:
+    """ygs.rs:195-206.  Returns the ordering that `apply_ordering` would consume (empty = the
+    reference's no-op, graph_ops.rs:1940)."""
+    return path_sgd_sort(graph, params, cfg)
+
+
+def default_layout_init(graph: FlatGraph, dims: int, seed: int) -> np.ndarray:
+    """Initial coordinates in Layout order.  Dimension 0 exactly as sgd.rs:832-853 (+end =
+    bp prefix, -end = prefix + length).  Dimensions >= 1: N(0,1)*sqrt(2N) like sgd.rs:836-849,
+    but drawn by Box-Muller from SplitMix64(seed) — the reference's rand_distr ziggurat stream
+    is not reproduced."""
+    from .graph import splitmix64_array
+    n = graph.n_nodes * 2 * dims
+    c = np.zeros((graph.n_nodes, 2, dims), dtype=np.float64)
+    if dims > 1:
+        r = splitmix64_array(seed, 2 * n)
+        u1 = ((r[:n] >> np.uint64(11)).astype(np.float64) + 1.0) / 9007199254740993.0
+        u2 = (r[n:] >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
+        z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+        c[:] = (z * np.sqrt(2.0 * graph.n_nodes)).reshape(graph.n_nodes, 2, dims)
+    c0 = hip.init_layout_dim0(graph, dims).reshape(graph.n_nodes, 2, dims)
+    c[:, :, 0] = c0[:, :, 0]
+    return np.ascontiguousarray(c.reshape(-1))
+
+
+def path_linear_sgd_layout(graph: FlatGraph, params: LayoutSGDParams, init: Optional[np.ndarray] = None,
+                           cfg=None, return_stats: bool = False):
+    """sgd.rs:773.  Returns a Layout; all-zero when the reference returns `Layout::new`
+    (sgd.rs:780-782,795-798)."""
+    D = params.dimensions
+    if graph.n_nodes == 0:
+        lay = Layout(D, 0)
+        return (lay, None) if return_stats else lay
+    if init is None:
+        init = default_layout_init(graph, D, params.seed)
+    rc, coords, st = hip.path_linear_sgd_layout_raw(graph, params, init, cfg=cfg)
+    lay = Layout(D, graph.n_nodes, coords if rc == hip.OK else None)
+    return (lay, st) if return_stats else lay

@@ -95,6 +95,8 @@ typedef struct gfs_launch_config {
 #define GFS_F_PLAIN_LOADS   1u        /* read positions with plain (L2-cacheable) loads instead
                                          of agent-scope relaxed atomic loads                 */
 #define GFS_F_NO_LDS_TABLES 2u        /* keep zeta/path tables in global memory              */
+#define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
+#define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
 
 typedef struct gfs_stats {
     uint64_t term_updates;            /* successful updates, counted where sgd.rs:579 counts */

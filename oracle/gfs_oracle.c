@@ -505,52 +505,101 @@ static int has_valid_paths(const gfo_graph *g) {                      /* sgd.rs:
 }
 
 /* ------------------------------------------------------------------------------------------
- * Deterministic mode.
+ * Deterministic mode, as a resumable state: streams keep their RNG across iterations.
  * ---------------------------------------------------------------------------------------- */
+struct gfo_state {
+    pidx pi;
+    gfo_params p;
+    double *etas, *zetas;
+    zipf_env z;
+    uint64_t T, D, quota_total, attempt_factor;
+    uint64_t *rng, *done, *att, *ntr;
+    gfo_term *trace; uint64_t trace_per_stream;
+    uint64_t total_upd, total_att, iterations;
+    double seconds;
+};
+
+void gfo_state_destroy(gfo_state *s) {
+    if (!s) return;
+    pidx_free(&s->pi);
+    free(s->etas); free(s->zetas); free(s->rng); free(s->done); free(s->att); free(s->ntr);
+    free(s);
+}
+
+int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas_in, const double *zetas_in,
+                     uint64_t dims, uint64_t n_streams, uint64_t stream_base, uint64_t quota_total,
+                     uint64_t attempt_factor, gfo_term *trace, uint64_t trace_per_stream, gfo_state **out) {
+    *out = NULL;
+    if (g->n_nodes == 0 || !has_valid_paths(g)) return 1;             /* sgd.rs:242-244, 258-261 */
+    if (n_streams == 0 || dims > GFO_MAX_DIMS) return -1;
+    gfo_state *s = (gfo_state *)calloc(1, sizeof *s);
+    if (!s) return -2;
+    if (pidx_build(g, 1, &s->pi)) { gfo_state_destroy(s); return -2; }
+    s->p = *p; s->T = n_streams; s->D = dims;
+    s->quota_total = quota_total ? quota_total : p->min_term_updates;
+    s->attempt_factor = attempt_factor ? attempt_factor : 64;
+    s->etas = (double *)malloc((p->iter_max + 1) * 8);
+    s->zetas = (double *)malloc(gfo_zeta_size(p) * 8);
+    if (etas_in) memcpy(s->etas, etas_in, (p->iter_max + 1) * 8); else gfo_schedule(p, s->etas);
+    if (zetas_in) memcpy(s->zetas, zetas_in, gfo_zeta_size(p) * 8); else gfo_zetas(p, s->zetas);
+    s->z = (zipf_env){ s->zetas, gfo_zeta_size(p), p->space, p->space_max, p->space_quantization_step };
+    s->rng = (uint64_t *)malloc(n_streams * 32);
+    s->done = (uint64_t *)malloc(n_streams * 8); s->att = (uint64_t *)malloc(n_streams * 8);
+    s->ntr = (uint64_t *)calloc(n_streams, 8);
+    for (uint64_t t = 0; t < n_streams; t++)
+        gfo_xoshiro_seed(p->seed + stream_base + t, s->rng + 4 * t);  /* sgd.rs:431-432 */
+    s->trace = trace; s->trace_per_stream = trace_per_stream;
+    *out = s;
+    return 0;
+}
+
+/* One batch: iteration k uses etas[k]; streams advance round-robin, one attempt each. */
+int gfo_state_run_iteration(gfo_state *s, uint64_t k, double *x) {
+    if (!s || k > s->p.iter_max) return -1;
+    const uint64_t T = s->T, D = s->D;
+    double t0 = now_s();
+    iter_state it; iter_consts(&s->p, s->etas, k, &it);
+    uint64_t base = s->quota_total / T, rem = s->quota_total % T;
+    memset(s->done, 0, T * 8); memset(s->att, 0, T * 8);
+    for (;;) {
+        int active = 0;
+        for (uint64_t t = 0; t < T; t++) {
+            uint64_t quota = base + (t < rem ? 1 : 0);
+            if (s->done[t] >= quota || s->att[t] >= s->attempt_factor * quota + 1024) continue;
+            active = 1;
+            s->att[t]++;
+            uint64_t sa, sb;
+            if (!sample_pair(&s->pi, 1, &s->z, &it, s->rng + 4 * t, &sa, &sb)) continue;
+            gfo_term tr;
+            int ok = D ? term_nd(&s->pi, 1, &it, s->rng + 4 * t, sa, sb, x, D, 0, NULL, &tr)
+                       : term_1d(&s->pi, 1, &it, sa, sb, x, 0, NULL, &tr);
+            if (!ok) continue;
+            s->done[t]++;
+            if (s->trace && s->ntr[t] < s->trace_per_stream) s->trace[t * s->trace_per_stream + s->ntr[t]++] = tr;
+        }
+        if (!active) break;
+    }
+    for (uint64_t t = 0; t < T; t++) { s->total_upd += s->done[t]; s->total_att += s->att[t]; }
+    s->iterations++;
+    s->seconds += now_s() - t0;
+    return 0;
+}
+
+void gfo_state_stats(const gfo_state *s, gfo_stats *st) {
+    st->term_updates = s->total_upd; st->attempts = s->total_att;
+    st->iterations = s->iterations; st->seconds = s->seconds;
+}
+
 static int sgd_det(const gfo_graph *g, const gfo_params *p, const double *etas_in, const double *zetas_in,
                    uint64_t T, uint64_t attempt_factor, double *x, uint64_t D /*0 = 1D*/,
                    gfo_term *trace, uint64_t trace_per_stream, gfo_stats *st) {
     if (st) memset(st, 0, sizeof *st);
-    if (g->n_nodes == 0 || !has_valid_paths(g)) return 1;             /* sgd.rs:242-244, 258-261 */
-    if (T == 0 || D > GFO_MAX_DIMS) return -1;
-    pidx pi;
-    if (pidx_build(g, 1, &pi)) { pidx_free(&pi); return -2; }
-    double *etas = NULL, *zetas = NULL;
-    if (!etas_in) { etas = (double *)malloc((p->iter_max + 1) * 8); gfo_schedule(p, etas); etas_in = etas; }
-    if (!zetas_in) { zetas = (double *)malloc(gfo_zeta_size(p) * 8); gfo_zetas(p, zetas); zetas_in = zetas; }
-    zipf_env z = { zetas_in, gfo_zeta_size(p), p->space, p->space_max, p->space_quantization_step };
-    uint64_t *rng = (uint64_t *)malloc(T * 32);
-    uint64_t *done = (uint64_t *)malloc(T * 8), *att = (uint64_t *)malloc(T * 8), *ntr = (uint64_t *)calloc(T, 8);
-    for (uint64_t t = 0; t < T; t++) gfo_xoshiro_seed(p->seed + t, rng + 4 * t);   /* sgd.rs:431-432 */
-    uint64_t base = p->min_term_updates / T, rem = p->min_term_updates % T;
-    uint64_t total_upd = 0, total_att = 0;
-    double t0 = now_s();
-    for (uint64_t k = 0; k <= p->iter_max; k++) {
-        iter_state it; iter_consts(p, etas_in, k, &it);
-        memset(done, 0, T * 8); memset(att, 0, T * 8);
-        for (;;) {
-            int active = 0;
-            for (uint64_t t = 0; t < T; t++) {
-                uint64_t quota = base + (t < rem ? 1 : 0);
-                if (done[t] >= quota || att[t] >= attempt_factor * quota + 1024) continue;
-                active = 1;
-                att[t]++;
-                uint64_t sa, sb;
-                if (!sample_pair(&pi, 1, &z, &it, rng + 4 * t, &sa, &sb)) continue;
-                gfo_term tr;
-                int ok = D ? term_nd(&pi, 1, &it, rng + 4 * t, sa, sb, x, D, 0, NULL, &tr)
-                           : term_1d(&pi, 1, &it, sa, sb, x, 0, NULL, &tr);
-                if (!ok) continue;
-                done[t]++;
-                if (trace && ntr[t] < trace_per_stream) trace[t * trace_per_stream + ntr[t]++] = tr;
-            }
-            if (!active) break;
-        }
-        for (uint64_t t = 0; t < T; t++) { total_upd += done[t]; total_att += att[t]; }
-    }
-    if (st) { st->term_updates = total_upd; st->attempts = total_att; st->iterations = p->iter_max + 1; st->seconds = now_s() - t0; }
-    free(rng); free(done); free(att); free(ntr); free(etas); free(zetas);
-    pidx_free(&pi);
+    gfo_state *s;
+    int rc = gfo_state_create(g, p, etas_in, zetas_in, D, T, 0, 0, attempt_factor, trace, trace_per_stream, &s);
+    if (rc) return rc;
+    for (uint64_t k = 0; k <= p->iter_max; k++) gfo_state_run_iteration(s, k, x);
+    if (st) gfo_state_stats(s, st);
+    gfo_state_destroy(s);
     return 0;
 }
 

@@ -111,6 +111,17 @@ int gfo_sgd_nd(const gfo_graph *g, const gfo_params *p, const double *etas, cons
                uint64_t n_streams, uint64_t attempt_factor, double *coords,
                gfo_term *trace, uint64_t trace_per_stream, gfo_stats *st);
 
+/* ---- the same, resumable: one call per iteration, streams keep their RNG in between.
+ * dims = 0 for 1D.  stream t is seeded seed + stream_base + t; quota_total (0 = min_term_updates)
+ * is this state's share of an iteration's updates (multi-rank tests). */
+typedef struct gfo_state gfo_state;
+int  gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas, const double *zetas,
+                      uint64_t dims, uint64_t n_streams, uint64_t stream_base, uint64_t quota_total,
+                      uint64_t attempt_factor, gfo_term *trace, uint64_t trace_per_stream, gfo_state **out);
+int  gfo_state_run_iteration(gfo_state *s, uint64_t k, double *x);
+void gfo_state_stats(const gfo_state *s, gfo_stats *st);
+void gfo_state_destroy(gfo_state *s);
+
 /* ---- reference-like mode (timed CPU baseline): p->nthreads Hogwild workers + 1 ms checker
  * thread (sgd.rs:366-407, 413-593).  flat=0: node lookup through a hash map and 8-byte step
  * arrays like the reference; flat=1: dense arrays, no hash map (optimised CPU variant).

@@ -1,0 +1,164 @@
+"""Host-side logic (CPU): GFA reader/writer, flattening, Layout, synthetic generators, sharding.
+Mirrors the reference's own unit tests where they exist (layout.rs:262-340, ygs.rs:247-303,
+graph_ops.rs:2051-2132, integration_tests.rs)."""
+import io
+
+import numpy as np
+import pytest
+
+from util import O, G, P, load, oracle_graph
+from gfasort_amd.layout import Layout, _fmt_f64, dim_name
+from gfasort_amd import distributed as D
+
+
+# ---- GFA reader (src/bin/gfasort.rs:88-167) --------------------------------------------------------
+def test_parse_gfa_simple():
+    g = load("simple.gfa")
+    assert g.node_ids.tolist() == list(range(1, 16))                  # S-line order = node_order
+    assert g.node_len[:3].tolist() == [8, 1, 1] and g.node_len[8] == 19
+    assert g.path_names == ["x"] and g.step_node.tolist() == [0, 2, 4, 5, 7, 8, 10, 11, 13, 14]
+    assert len(g.edges) == 20 and not g.step_is_rev.any()
+
+
+def test_parse_gfa_node_order_duplicates_and_absent_nodes():
+    txt = "S\t7\tACG\nS\t3\tA\nS\t7\tTTTT\nP\tp\t3+,7-,9+\t*\nL\t7\t+\t3\t-\t0M\nL\t3\t+\t7\t-\t0M\n"
+    g = G.parse_gfa(txt)
+    assert g.node_ids.tolist() == [7, 3]                              # 7 pushed once (graph_ops.rs:619-621)
+    assert g.node_len.tolist() == [4, 1]                              # sequence overwritten by the 2nd S line
+    assert g.step_node.tolist() == [1, 0, G.NO_NODE]                  # 9 is not a node
+    assert g.step_is_rev.tolist() == [0, 1, 0]
+    assert len(g.edges) == 1                                          # 3+->7- is the complement of 7+->3-
+    pos, plen = g.step_positions()
+    assert pos.tolist() == [0, 1, 5] and plen.tolist() == [5]         # absent node adds 0 bp (sgd.rs:52-54)
+
+
+def test_parse_gfa_rejects_bad_ids():
+    with pytest.raises(ValueError):
+        G.parse_gfa("S\tabc\tA\n")
+
+
+def test_write_gfa_sorted_roundtrip_counts():
+    # integration_tests.rs:23-51,175-206: sorting keeps node / edge / path counts
+    g = load("DRB1-3123.gfa")
+    order = np.random.default_rng(0).permutation(g.n_nodes)
+    txt = G.write_gfa_sorted(g, order)
+    g2 = G.parse_gfa(txt)
+    assert (g2.n_nodes, len(g2.edges), g2.n_paths, g2.n_steps) == (g.n_nodes, len(g.edges), g.n_paths, g.n_steps)
+    assert g2.node_ids.tolist() == list(range(1, g.n_nodes + 1))      # new id = rank+1 (graph_ops.rs:1956)
+    assert txt.startswith("H\tVN:Z:1.0\n")
+    # the node at rank r carries the sequence of the node that was ordered r-th
+    assert g2.sequences[5] == g.sequences[int(order[5])]
+    # path step sequences are preserved
+    seq = lambda gg, s: gg.sequences[int(gg.step_node[s])]
+    assert all(seq(g, s) == seq(g2, s) for s in range(0, g.n_steps, 97))
+    assert np.array_equal(g.step_is_rev, g2.step_is_rev)
+
+
+def test_apply_ordering_ids():
+    g = load("simple.gfa")
+    o2n = G.apply_ordering_ids(g, np.array([2, 0, 1]))
+    assert o2n == {3: 1, 1: 2, 2: 3}
+
+
+# ---- Layout (src/layout.rs:258-341) ------------------------------------------------------------------
+def test_layout_new_get_set():
+    lay = Layout(2, 10)
+    assert (lay.dimensions, lay.num_nodes, len(lay.coords)) == (2, 10, 40)
+    lay = Layout(2, 5)
+    lay.set(2, 0, 0, 100.0); lay.set(2, 0, 1, 200.0); lay.set(2, 1, 0, 150.0); lay.set(2, 1, 1, 250.0)
+    assert (lay.x_plus(2), lay.y_plus(2), lay.x_minus(2), lay.y_minus(2)) == (100.0, 200.0, 150.0, 250.0)
+    assert lay.index(2, 1, 1) == 2 * 2 * 2 + 1 * 2 + 1
+
+
+def test_layout_distance_345():
+    lay = Layout(2, 2)
+    lay.set(1, 0, 0, 3.0); lay.set(1, 0, 1, 4.0)
+    assert abs(lay.distance(0, 0, 1, 0) - 5.0) < 1e-10
+
+
+def test_layout_from_vectors():
+    lay = Layout.from_vectors([np.array([1.0, 2.0, 3.0, 4.0]), np.array([10.0, 20.0, 30.0, 40.0])])
+    assert (lay.num_nodes, lay.dimensions) == (2, 2)
+    assert (lay.x_plus(0), lay.y_plus(0), lay.x_minus(0), lay.y_minus(0), lay.x_plus(1), lay.y_plus(1)) == \
+        (1.0, 10.0, 2.0, 20.0, 3.0, 30.0)
+
+
+def test_layout_tsv_roundtrip():
+    lay = Layout(2, 3)
+    vals = [1.5, 2.5, 3.5, 4.5, 10.0, 20.0, 30.0, 40.0, 100.0, 200.0, 300.0, 400.0]
+    lay.coords[:] = vals
+    txt = lay.to_tsv()
+    assert txt.split("\n")[0] == "idx\tx+\ty+\tx-\ty-"
+    assert txt.split("\n")[2] == "1\t10\t20\t30\t40"                   # Rust `{}` prints 10.0 as "10"
+    back = Layout.read_tsv(io.StringIO(txt))
+    assert (back.dimensions, back.num_nodes) == (2, 3) and np.allclose(back.coords, lay.coords, atol=1e-10)
+
+
+def test_rust_float_display():
+    assert _fmt_f64(1.0) == "1" and _fmt_f64(-0.5) == "-0.5" and _fmt_f64(1e21) == "1000000000000000000000"
+    assert _fmt_f64(1e-7) == "0.0000001" and _fmt_f64(0.1 + 0.2) == "0.30000000000000004"
+    assert [dim_name(d) for d in range(6)] == ["x", "y", "z", "w", "d", "d"]
+
+
+# ---- synthetic generators --------------------------------------------------------------
+def test_synth_chain_structure():
+    g = G.synth_chain(1000, 1)
+    assert (g.n_nodes, g.n_steps, g.n_paths) == (1000, 1000, 1)
+    assert sorted(g.node_ids.tolist()) == list(range(1, 1001))
+    assert g.node_ids.tolist() != list(range(1, 1001))                # S lines are block-shuffled
+    assert g.step_node_id.tolist() == list(range(1, 1001))            # the path is the chain
+    assert g.node_ids[g.step_node].tolist() == list(range(1, 1001))
+    assert 1 <= g.node_len.min() and g.node_len.max() <= 16
+    # shuffle stays inside blocks of 64 ids
+    assert all(abs(int(nid) - 1 - k) < 64 and (int(nid) - 1) // 64 == k // 64 for k, nid in enumerate(g.node_ids))
+    g2 = G.synth_chain(1000, 1)
+    assert np.array_equal(g.node_ids, g2.node_ids) and np.array_equal(g.node_len, g2.node_len)
+
+
+def test_synth_windows_c3_shape_small():
+    g = G.synth_windows(10000, 8, 2000, 2)
+    assert (g.n_nodes, g.n_paths, g.n_steps) == (10000, 8, 16000)
+    first = g.path_first_step.astype(int)
+    for p in range(8):
+        ids = g.step_node_id[first[p]:first[p + 1]]
+        o = (p * (10000 - 2000)) // 7
+        assert ids[0] == o + 1 and ids[-1] == o + 2000 and np.all(np.diff(ids.astype(int)) == 1)
+    y = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    assert y.min_term_updates == 16000 and y.eta_max == 2000.0 ** 2
+
+
+def test_synth_gfa_text_roundtrip():
+    g = G.synth_windows(300, 3, 120, 5)
+    g2 = G.parse_gfa(G.synth_to_gfa_text(g))
+    assert np.array_equal(g.node_ids, g2.node_ids) and np.array_equal(g.node_len, g2.node_len)
+    assert np.array_equal(g.step_node, g2.step_node) and np.array_equal(g.path_first_step, g2.path_first_step)
+
+
+def test_splitmix_array_matches_oracle():
+    assert G.splitmix64_array(1234567, 5).tolist() == O.splitmix64_stream(1234567, 5)
+
+
+# ---- multi-GPU sharding helpers ----------------------------------------------------------------------------
+def test_shard_paths_balanced_and_complete():
+    counts = np.array([100, 90, 80, 10, 10, 10, 5, 5])
+    shards = D.shard_paths(counts, 3)
+    assert sorted(p for s in shards for p in s) == list(range(8))
+    loads = [int(counts[s].sum()) for s in shards]
+    assert max(loads) - min(loads) <= 20
+    assert D.shard_paths(counts, 1) == [list(range(8))]
+
+
+def test_shard_quotas_sum_exactly():
+    for total, steps in [(10_000_000, [1250000] * 8), (35059, [17000, 18059]), (7, [1, 1, 1]), (5, [0, 10])]:
+        q = D.shard_quotas(total, steps)
+        assert sum(q) == total and all(v >= 0 for v in q)
+    assert D.shard_quotas(100, [0, 10]) == [0, 100]
+
+
+def test_subgraph_keeps_nodes_and_selected_paths():
+    g = load("DRB1-3123.gfa")
+    sub = D.subgraph(g, [1, 4])
+    counts = g.path_step_counts()
+    assert sub.n_nodes == g.n_nodes and sub.n_paths == 2 and sub.n_steps == counts[1] + counts[4]
+    f = g.path_first_step.astype(int)
+    assert np.array_equal(sub.step_node[:counts[1]], g.step_node[f[1]:f[2]])
