@@ -37,5 +37,34 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(CSRC, "host")
+HOST_SOURCES = ["graph.cpp", "sgd.cpp"]
+HOST_HEADERS = ["graph.hpp", "sgd.hpp"]
+BINDIR = os.path.join(HERE, "bin")
+CLI = os.path.join(BINDIR, "gfasort_hip")
+SELFTEST = os.path.join(BINDIR, "host_selftest")
+CXX_FLAGS = ["-O2", "-std=c++17", "-Wall", "-ffp-contract=off"]
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host mirror (graph / GFA / params / Layout / SGD wrappers), its CLI `gfasort_hip`
+    and `host_selftest`; both link libgfasort_hip.so through an $ORIGIN-relative rpath."""
+    build_hip(force=False, verbose=verbose)
+    os.makedirs(BINDIR, exist_ok=True)
+    deps = [os.path.join(HOST_DIR, f) for f in HOST_SOURCES + HOST_HEADERS + ["main.cpp", "selftest.cpp"]] + [LIB]
+    out = []
+    for exe, main in ((CLI, "main.cpp"), (SELFTEST, "selftest.cpp")):
+        if force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+            cmd = [os.environ.get("CXX", "g++")] + CXX_FLAGS + ["-o", exe, os.path.join(HOST_DIR, main)] + \
+                  [os.path.join(HOST_DIR, f) for f in HOST_SOURCES] + \
+                  ["-L" + LIBDIR, "-lgfasort_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

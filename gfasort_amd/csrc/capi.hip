@@ -281,6 +281,11 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     if (c->quota_total / T + 1 > 0xFFFFFFFFull) return fail(GFS_E_UNSUPPORTED, "per-stream quota exceeds 2^32");
     if (c->cfg.attempt_factor == 0) c->cfg.attempt_factor = 64;
     if (c->cfg.attempt_factor > 0xFFFFFFFFull) return fail(GFS_E_ARG, "attempt_factor too large");
+    {
+        uint32_t b = (c->cfg.flags >> 16) & 0xFFu;
+        if (b > 1 && (T % 64 != 0 || (b != 4 && b != 8 && b != 16 && b != 64)))
+            return fail(GFS_E_ARG, "bundled sampling needs n_streams % 64 == 0 and a bundle of 4, 8, 16 or 64");
+    }
     c->atomic_loads = !(c->cfg.flags & GFS_F_PLAIN_LOADS);
     size_t lds = (size_t)c->n_paths * sizeof(uint4) + (size_t)c->zlen_staged * 8;
     c->lds_tables = !(c->cfg.flags & GFS_F_NO_LDS_TABLES) && lds <= 48 * 1024;
@@ -465,6 +470,7 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
     a.dbg = (c->cfg.flags >> 8) & 0xFFu;
+    a.bundle = (c->cfg.flags >> 16) & 0xFFu;      // EXPERIMENTAL: GFS_F_BUNDLE(n)
     iter_consts(c, k, a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
     if (c->events_used == c->events.size()) {

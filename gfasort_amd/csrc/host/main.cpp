@@ -1,0 +1,152 @@
+// gfasort_hip — CLI with the flag surface of the reference binary (src/bin/gfasort.rs:49-86),
+// running the `Y` (path-guided SGD sort) and `L` (nD layout) pipeline steps on the MI355X
+// engine.  The other pipeline characters (g, s, S, u) belong to subsystems that are out of
+// scope for this build: they are rejected with a clear message.
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+
+#include "sgd.hpp"
+
+using namespace gfasort;
+
+struct Args {
+    std::string input, output, pipeline = "sYgs", layout_out;
+    size_t iter_max = 100, threads = 1, dimensions = 2, layout_iter = 30;
+    unsigned verbose = 1;
+    uint64_t streams = 0; uint32_t flags = 0;      // HIP launch shape (extra, not in the reference)
+};
+
+static void usage() {
+    std::cerr <<
+        "Usage: gfasort_hip -i <in.gfa> -o <out.gfa> [-p PIPELINE] [--iter-max N] [-t N] [-v N]\n"
+        "                   [--dimensions D] [--layout-out FILE] [--layout-iter N] [--streams N]\n"
+        "Pipeline characters: Y = path-guided SGD sort, L = nD layout (HIP engine).\n"
+        "g, s, S, u exist in the reference but are not part of this build.\n";
+}
+
+static bool parse_args(int argc, char **argv, Args &a) {
+    auto need = [&](int &i) -> const char * { if (i + 1 >= argc) { std::cerr << "error: missing value for " << argv[i] << "\n"; return nullptr; } return argv[++i]; };
+    for (int i = 1; i < argc; ++i) {
+        std::string f = argv[i];
+        const char *v;
+        if (f == "-i" || f == "--input") { if (!(v = need(i))) return false; a.input = v; }
+        else if (f == "-o" || f == "--output") { if (!(v = need(i))) return false; a.output = v; }
+        else if (f == "-p" || f == "--pipeline") { if (!(v = need(i))) return false; a.pipeline = v; }
+        else if (f == "--iter-max") { if (!(v = need(i))) return false; a.iter_max = std::stoull(v); }
+        else if (f == "-t" || f == "--threads") { if (!(v = need(i))) return false; a.threads = std::stoull(v); }
+        else if (f == "-v" || f == "--verbose") { if (!(v = need(i))) return false; a.verbose = (unsigned)std::stoul(v); }
+        else if (f == "--dimensions") { if (!(v = need(i))) return false; a.dimensions = std::stoull(v); }
+        else if (f == "--layout-out") { if (!(v = need(i))) return false; a.layout_out = v; }
+        else if (f == "--layout-iter") { if (!(v = need(i))) return false; a.layout_iter = std::stoull(v); }
+        else if (f == "--streams") { if (!(v = need(i))) return false; a.streams = std::stoull(v); }
+        else if (f == "--hip-flags") { if (!(v = need(i))) return false; a.flags = (uint32_t)std::stoul(v); }
+        else if (f == "-h" || f == "--help") { usage(); exit(0); }
+        else { std::cerr << "error: unexpected argument '" << f << "'\n"; return false; }
+    }
+    if (a.input.empty() || a.output.empty()) { std::cerr << "error: -i and -o are required\n"; return false; }
+    return true;
+}
+
+static int validate_pipeline(const std::string &p) {                  // gfasort.rs:169-180
+    for (char c : p) {
+        switch (c) {
+            case 'Y': case 'L': break;
+            case 'g': case 's': case 'S': case 'u':
+                std::cerr << "Error: pipeline step '" << c << "' is part of the reference but not of this build "
+                             "(only Y = SGD and L = layout run on the HIP engine)\n";
+                return 1;
+            default:
+                std::cerr << "Error: Unknown pipeline character '" << c
+                          << "'. Valid: Y (SGD), g (groom), s (topo-sort), S (priority-topo-sort), u (unchop), L (layout)\n";
+                return 1;
+        }
+    }
+    if (p.empty()) { std::cerr << "Error: Pipeline cannot be empty\n"; return 1; }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    Args args;
+    if (!parse_args(argc, argv, args)) { usage(); return 2; }
+    if (validate_pipeline(args.pipeline)) return 1;
+    auto t_start = std::chrono::steady_clock::now();
+    if (args.verbose >= 1) std::cerr << "[gfasort] reading " << args.input << "\n";
+    std::string content;
+    {
+        std::ifstream in(args.input, std::ios::binary);
+        if (!in) { std::cerr << "Error reading file: " << std::strerror(errno) << "\n"; return 1; }
+        std::ostringstream ss; ss << in.rdbuf(); content = ss.str();
+    }
+    BidirectedGraph graph;
+    try { graph = parse_gfa(content); }
+    catch (const std::exception &e) { std::cerr << "Error parsing GFA: " << e.what() << "\n"; return 1; }
+    if (args.verbose >= 1)
+        std::cerr << "[gfasort] loaded " << graph.node_count() << " nodes, " << graph.edges.size() << " edges, "
+                  << graph.paths.size() << " paths\n";
+    if (args.verbose >= 2) std::cerr << "[gfasort] pipeline: " << args.pipeline << "\n";
+
+    YgsParams ygs = YgsParams::from_graph(graph, (uint8_t)args.verbose, args.threads);      // gfasort.rs:222-224
+    PathSGDParams sgd_params = ygs.path_sgd;
+    sgd_params.iter_max = args.iter_max;
+    LayoutSGDParams layout_params = LayoutSGDParams::from_graph(graph, args.dimensions, args.threads);   // :227-229
+    layout_params.iter_max = args.layout_iter;
+    layout_params.progress = args.verbose >= 2;
+    HipOptions opt; opt.cfg.n_streams = args.streams; opt.cfg.flags = args.flags;
+
+    bool have_layout = false;
+    Layout layout;
+    try {
+        size_t step = 0;
+        for (char c : args.pipeline) {
+            ++step;
+            if (args.verbose >= 1)
+                std::cerr << "[gfasort] [" << step << "/" << args.pipeline.size() << "] "
+                          << (c == 'Y' ? std::string("SGD") : std::to_string(args.dimensions) + "D layout") << "\n";
+            gfs_stats st{};
+            if (c == 'Y') {
+                sgd_sort_only(graph, sgd_params, (uint8_t)args.verbose, opt, &st);          // gfasort.rs:250-252
+            } else {
+                layout = path_linear_sgd_layout(graph, layout_params, opt, &st);            // :265-267
+                have_layout = true;
+                if (args.verbose >= 1) {
+                    double stress = calculate_layout_stress(graph, layout, 10000);
+                    char buf[64]; snprintf(buf, sizeof buf, "%.6f", stress);
+                    std::cerr << "[gfasort] layout stress: " << buf << "\n";
+                }
+            }
+            if (args.verbose >= 1 && st.iterations)
+                std::cerr << "[gfasort_hip] " << st.term_updates << " term updates in " << st.iterations << " iterations on "
+                          << st.n_streams << " streams; kernels " << st.kernel_ms << " ms ("
+                          << (st.kernel_ms > 0 ? (double)st.term_updates / st.kernel_ms / 1e6 : 0.0) << " G updates/s), call "
+                          << st.total_ms << " ms\n";
+        }
+    } catch (const std::exception &e) {
+        std::cerr << "Error: " << e.what() << "\n";
+        return 1;
+    }
+    if (have_layout) {
+        if (!args.layout_out.empty()) {
+            if (args.verbose >= 1) std::cerr << "[gfasort] writing layout to " << args.layout_out << "\n";
+            std::ofstream f(args.layout_out, std::ios::binary);
+            if (!f) { std::cerr << "Error creating layout file: " << std::strerror(errno) << "\n"; return 1; }
+            layout.write_tsv(f);
+        } else if (args.verbose >= 1) {
+            std::cerr << "[gfasort] warning: layout computed but --layout-out not specified\n";
+        }
+    }
+    if (args.verbose >= 1) std::cerr << "[gfasort] writing " << args.output << "\n";
+    {
+        std::ofstream f(args.output, std::ios::binary);
+        if (!f) { std::cerr << "Error writing output file: " << std::strerror(errno) << "\n"; return 1; }
+        graph.write_gfa(f);
+    }
+    if (args.verbose >= 1) {
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        std::cerr << "[gfasort] done (" << s << " s wall)\n";
+    }
+    return 0;
+}

@@ -96,6 +96,7 @@ struct KArgs {
     uint32_t attempt_factor, trace_per_stream;
     uint32_t space, space_max, space_q;
     uint32_t dbg;                  // diagnostic ablation bits (GFS_F_DBG_* >> 8), 0 in production
+    uint32_t bundle, _pad2;        // lanes per sampling bundle (1 = reference streams)
     IterConsts it;
 };
 
@@ -154,6 +155,73 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
     sa = step_idx;                                                                     // :502
     sb = first + rank_b;                                                               // :503
     rb = a.step_rec[sb];
+    cnt_out = cnt; path_out = path;
+    return true;
+}
+
+// Bundled sampler (EXPERIMENTAL): B adjacent lanes share ONE draw of (step a0, Zipf/uniform,
+// direction, jump) made by the bundle's first lane from its own stream; lane l of the bundle
+// uses rank_a = (rank_a0 + l) mod cnt and the same signed jump (Zipf branch, clamped to the
+// path like sgd.rs:474,489) or rank_b = (rank_b0 + l) mod cnt (uniform branch).  Every lane's
+// term keeps the reference's marginal distribution up to path-end effects of O(B/cnt); what
+// changes is the correlation between concurrent terms, which buys hardware coalescing of the
+// record loads, position loads and atomics (B consecutive steps = 16*B contiguous bytes).
+template <bool LDS_TABLES, int B>
+__device__ __forceinline__ bool sample_pair_bundled(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
+                                                    Rng &rng, uint4 &ra, uint4 &rb, uint32_t &sa, uint32_t &sb,
+                                                    uint32_t &cnt_out, uint32_t &path_out) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (B - 1);
+    const int lead = lane & ~(B - 1);
+    uint32_t first = 0, cnt = 0, rank_a = 0, rank_b = 0, path = 0, zipf = 0, okl = 0;
+    if (sub == 0) {
+        uint32_t step_idx = rng.uniform32(a.n_steps, a.steps_thresh);
+        uint4 r0 = a.step_rec[step_idx];
+        path = r0.y & 0x7FFFFFFFu;
+        uint4 pr = path_tab[path];
+        first = pr.x; cnt = pr.y;
+        if (cnt != 1u) {
+            okl = 1;
+            rank_a = step_idx - first;
+            rank_b = rank_a;
+            if (a.it.cooling || rng.flip() == 1u) {
+                zipf = 1;
+                bool back = false, fwd = false;
+                if (rank_a > 0u && (rng.flip() == 1u || rank_a == cnt - 1u)) back = true;
+                else if (rank_a < cnt - 1u) fwd = true;
+                if (back || fwd) {
+                    uint32_t room = back ? rank_a : (cnt - rank_a - 1u);
+                    uint32_t jump = a.space < room ? a.space : room;
+                    double zeta = zeta_tab[space_index(a, jump)];
+                    uint32_t z = dirty_zipf(a.it, jump, zeta, rng.f64());
+                    if (back) rank_b = rank_a >= z ? rank_a - z : 0u;
+                    else { uint64_t t = (uint64_t)rank_a + z; rank_b = t < cnt - 1u ? (uint32_t)t : cnt - 1u; }
+                }
+            } else {
+                rank_b = rng.uniform32(cnt, pr.z);
+            }
+        }
+    }
+    okl = __shfl(okl, lead, 64);
+    if (!okl) return false;
+    first = __shfl(first, lead, 64); cnt = __shfl(cnt, lead, 64); path = __shfl(path, lead, 64);
+    rank_a = __shfl(rank_a, lead, 64); rank_b = __shfl(rank_b, lead, 64); zipf = __shfl(zipf, lead, 64);
+    uint32_t ra_l, rb_l;
+    if (cnt < 2u * B) {                 // short path: only the bundle leader acts (keeps tiny graphs exact)
+        if (sub != 0) return false;
+        ra_l = rank_a; rb_l = rank_b;
+    } else {
+        ra_l = rank_a + (uint32_t)sub; if (ra_l >= cnt) ra_l -= cnt;
+        if (zipf) {
+            int64_t t = (int64_t)ra_l + ((int64_t)rank_b - (int64_t)rank_a);
+            rb_l = t < 0 ? 0u : (t > (int64_t)cnt - 1 ? cnt - 1u : (uint32_t)t);
+        } else {
+            rb_l = rank_b + (uint32_t)sub; if (rb_l >= cnt) rb_l -= cnt;
+        }
+    }
+    if (ra_l == rb_l) return false;
+    sa = first + ra_l; sb = first + rb_l;
+    ra = a.step_rec[sa]; rb = a.step_rec[sb];
     cnt_out = cnt; path_out = path;
     return true;
 }

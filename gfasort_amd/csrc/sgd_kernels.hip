@@ -63,7 +63,7 @@ __device__ __forceinline__ void flush_counters(const KArgs &a, uint32_t done, ui
 // ------------------------------------------------------------------------------------------
 // K1: 1D
 // ------------------------------------------------------------------------------------------
-template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE, int BUNDLE>
 __global__ void sgd1d_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
@@ -81,10 +81,17 @@ __global__ void sgd1d_kernel(const KArgs a) {
         const uint32_t max_att = max_att64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_att64;
         uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
         double *x = a.x;
-        while (done < quota && att < max_att) {
-            ++att;
+        for (;;) {
+            bool want = done < quota && att < max_att;
+            if (BUNDLE == 1) { if (!want) break; }
+            else if (__ballot(want) == 0ull) break;                 // bundle mode: wave-uniform trip count
             uint4 ra, rb; uint32_t sa, sb, cnt, path;
-            if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) continue;
+            bool got;
+            if (BUNDLE == 1) got = sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path);
+            else got = sample_pair_bundled<LDS_TABLES, BUNDLE>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path);
+            if (!want) continue;
+            ++att;
+            if (!got) continue;
             double term_dist = fabs(rec_pos(ra) - rec_pos(rb));                        // sgd.rs:513
             if (term_dist == 0.0) continue;                                            // :514
             double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                       // :518-520
@@ -202,18 +209,30 @@ __global__ void sgdnd_kernel(const KArgs a) {
 }
 
 // ---- host-side launch dispatch -------------------------------------------------------------
-template <bool L, bool A>
+template <bool L, bool A, int B>
 static hipError_t launch_1d_t(const KArgs &a, bool trace, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (trace) hipLaunchKernelGGL((sgd1d_kernel<L, A, true>), grid, block, lds, st, a);
-    else       hipLaunchKernelGGL((sgd1d_kernel<L, A, false>), grid, block, lds, st, a);
+    if (trace) hipLaunchKernelGGL((sgd1d_kernel<L, A, true, B>), grid, block, lds, st, a);
+    else       hipLaunchKernelGGL((sgd1d_kernel<L, A, false, B>), grid, block, lds, st, a);
     return hipGetLastError();
+}
+template <int B>
+static hipError_t launch_1d_b(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                              dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (lds_tables) return atomic_loads ? launch_1d_t<true, true, B>(a, trace, grid, block, lds, st)
+                                        : launch_1d_t<true, false, B>(a, trace, grid, block, lds, st);
+    return atomic_loads ? launch_1d_t<false, true, B>(a, trace, grid, block, 0, st)
+                        : launch_1d_t<false, false, B>(a, trace, grid, block, 0, st);
 }
 hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
                      dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (lds_tables) return atomic_loads ? launch_1d_t<true, true>(a, trace, grid, block, lds, st)
-                                        : launch_1d_t<true, false>(a, trace, grid, block, lds, st);
-    return atomic_loads ? launch_1d_t<false, true>(a, trace, grid, block, 0, st)
-                        : launch_1d_t<false, false>(a, trace, grid, block, 0, st);
+    switch (a.bundle) {
+        case 0: case 1: return launch_1d_b<1>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 4:  return launch_1d_b<4>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 8:  return launch_1d_b<8>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 16: return launch_1d_b<16>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 64: return launch_1d_b<64>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <int D, bool L, bool A>

@@ -95,6 +95,8 @@ typedef struct gfs_launch_config {
 #define GFS_F_PLAIN_LOADS   1u        /* read positions with plain (L2-cacheable) loads instead
                                          of agent-scope relaxed atomic loads                 */
 #define GFS_F_NO_LDS_TABLES 2u        /* keep zeta/path tables in global memory              */
+#define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* EXPERIMENTAL: n in {4,8,16,64} adjacent lanes share
+                                         one sampled (step, jump) and take consecutive steps  */
 #define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
 #define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
 

@@ -109,3 +109,144 @@ def test_sampler_trace_full_width_nd():
     assert np.array_equal(tr["i"], tr_ref["i"]) and np.array_equal(tr["j"], tr_ref["j"])
     assert np.array_equal(tr["d_ij"].view(np.uint64), tr_ref["d_ij"].view(np.uint64))
     ctx.close()
+
+
+# ---- committed golden vectors (second target besides the live oracle) -------------------------------
+def test_replay_matches_committed_golden():
+    import hashlib
+    import json
+    import os
+    from util import GOLDEN
+    with open(os.path.join(GOLDEN, "oracle_golden.json")) as fh:
+        golden = json.load(fh)
+    for name, ent in golden["sgd_1d_single_stream"].items():
+        g = load(name)
+        p = _ygs(g, ent["iter_max"])
+        rc, x, st = hip.path_linear_sgd_raw(g, p, cfg=hip.make_config(n_streams=1))
+        assert rc == 0 and (st.term_updates, st.attempts) == (ent["term_updates"], ent["attempts"])
+        hx = [format(int(v), "016x") for v in x.view(np.uint64)]
+        if "x" in ent:
+            assert hx == ent["x"]
+        else:
+            assert hx[:32] == ent["x_head"] and hashlib.sha256(x.tobytes()).hexdigest() == ent["x_sha256"]
+    ent = golden["sgd_nd_single_stream"]["DRB1-3123.gfa"]
+    g = load("DRB1-3123.gfa")
+    p = P.LayoutSGDParams.from_graph(g, 2, 1)
+    p.iter_max, p.min_term_updates = ent["iter_max"], ent["min_term_updates"]
+    rc, c, st = hip.path_linear_sgd_layout_raw(g, p, gaussian_init(g, 2, 7), cfg=hip.make_config(n_streams=1))
+    assert hashlib.sha256(c.tobytes()).hexdigest() == ent["coords_sha256"]
+
+
+# ---- edge cases the reference handles -----------------------------------------------------------------
+def test_nothing_to_do_and_absent_nodes():
+    # only single-step paths -> empty result (sgd.rs:258-261)
+    g1 = G.parse_gfa("S\t1\tAC\nS\t2\tG\nP\ta\t1+\t*\nP\tb\t2+\t*\n")
+    rc, x, st = hip.path_linear_sgd_raw(g1, P.YgsParams.from_graph(g1, 0, 1).path_sgd)
+    assert rc == hip.NOTHING_TO_DO
+    from gfasort_amd import sgd as S
+    assert S.path_sgd_sort(g1, P.YgsParams.from_graph(g1, 0, 1).path_sgd).shape[0] == 0
+    lay = S.path_linear_sgd_layout(g1, P.LayoutSGDParams.from_graph(g1, 2, 1))
+    assert lay.num_nodes == 2 and not lay.coords.any()
+    # steps on ids that are not nodes are skipped (sgd.rs:525-538) and cost no bp (sgd.rs:52-54)
+    txt = "".join(f"S\t{i}\t{'A' * (1 + i % 5)}\n" for i in range(1, 41)) + \
+        "P\tp\t" + ",".join(f"{i}+" for i in list(range(1, 21)) + [99] + list(range(21, 41))) + "\t*\n" + \
+        "P\tq\t7+\t*\n"
+    g2 = G.parse_gfa(txt)
+    assert int((g2.step_node == G.NO_NODE).sum()) == 1
+    p = P.YgsParams.from_graph(g2, 0, 1).path_sgd
+    og, op = oracle_graph(g2), oracle_params(p)
+    x_ref = O.init_positions(og)
+    rc, st, _ = O.sgd_1d(og, op, x_ref, n_streams=1)
+    rc, x, hst = hip.path_linear_sgd_raw(g2, p, cfg=hip.make_config(n_streams=1))
+    assert rc == 0 and hst.attempts == st.attempts and hst.attempts > hst.term_updates
+    assert np.array_equal(x.view(np.uint64), x_ref.view(np.uint64))
+
+
+def test_self_loop_path_nd_replay():
+    """A path that revisits nodes: nD terms with idx_i == idx_j take the reference's
+    'second store wins' branch (sgd.rs:1143-1149)."""
+    txt = "".join(f"S\t{i}\t{'ACGT'[:1 + i % 4]}\n" for i in range(1, 9)) + \
+        "P\tp\t1+,2+,3+,2+,3-,4+,4+,5+,1-,6+,7+,8+,7-,8+\t*\n"
+    g = G.parse_gfa(txt)
+    p = P.LayoutSGDParams.from_graph(g, 2, 1)
+    p.iter_max = 20
+    og, op = oracle_graph(g), oracle_params(p)
+    c0 = gaussian_init(g, 2, 3)
+    c_ref = c0.copy()
+    O.sgd_nd(og, op, c_ref, n_streams=1)
+    rc, c, st = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(n_streams=1))
+    assert rc == 0 and np.array_equal(c.view(np.uint64), c_ref.view(np.uint64))
+
+
+# ---- full width: counts, quality (P2) and unique-optimum order (P1) at BASELINE sizes -----------------
+def _chain_order_ok(g, x):
+    ids = g.node_ids[hip.sort_order(x).astype(np.int64)].astype(np.int64)
+    n = g.n_nodes
+    return np.array_equal(ids, np.arange(1, n + 1)) or np.array_equal(ids, np.arange(n, 0, -1))
+
+
+def test_full_width_drb1_quality_matches_oracle():
+    g = load("DRB1-3123.gfa")
+    p = _ygs(g, 100)
+    og, op = oracle_graph(g), oracle_params(p)
+    x_ref = O.init_positions(og)
+    s0 = O.stress_1d(og, x_ref, 100000)
+    O.sgd_1d(og, op, x_ref, n_streams=8)
+    s_ref = O.stress_1d(og, x_ref, 100000)
+    rc, x, st = hip.path_linear_sgd_raw(g, p)
+    assert rc == 0 and st.term_updates == 101 * p.min_term_updates and st.n_streams > 1000
+    s_gpu = O.stress_1d(og, x, 100000)
+    assert s_ref < 0.5 * s0
+    assert abs(s_gpu - s_ref) < 0.1 * s_ref, (s0, s_ref, s_gpu)      # P2: within 10 % at equal update counts
+
+
+def test_c2_chain_100k_sorts_exactly():
+    g = G.synth_chain(100_000, 1)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd                     # -p Y, iter_max 100
+    rc, x, st = hip.path_linear_sgd_raw(g, p)
+    assert rc == 0 and st.term_updates == 101 * 100_000
+    assert _chain_order_ok(g, x)
+
+
+def test_c3_full_size_sorts_exactly_and_counts():
+    """BASELINE configs[2]: 1M nodes / 64 paths / 10M steps, -p Y --iter-max 200 => 2.01e9 updates."""
+    g = G.synth_windows(1_000_000, 64, 156_250, 2)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 200
+    assert (p.min_term_updates, p.eta_max) == (10_000_000, 156250.0 ** 2)
+    rc, x, st = hip.path_linear_sgd_raw(g, p)
+    assert rc == 0 and st.term_updates == 201 * 10_000_000 and st.iterations == 201
+    assert np.isfinite(x).all() and _chain_order_ok(g, x)
+    # sorted layout reproduces path distances: consecutive nodes are node_len apart
+    order = hip.sort_order(x).astype(np.int64)
+    gaps = np.abs(np.diff(x[order]))
+    want = g.node_len[order][:-1] if g.node_ids[order[0]] == 1 else g.node_len[order][1:]
+    assert np.max(np.abs(gaps - want)) < 1e-3
+
+
+def test_c4_layout_full_size():
+    """BASELINE configs[3]: the C3 graph, -p L --dimensions 2 (31 x 1e8 = 3.1e9 updates)."""
+    from gfasort_amd import sgd as S
+    g = G.synth_windows(1_000_000, 64, 156_250, 2)
+    p = P.LayoutSGDParams.from_graph(g, 2, 1)
+    assert (p.min_term_updates, p.space, p.iter_max) == (100_000_000, 156_250, 30)
+    lay, st = S.path_linear_sgd_layout(g, p, return_stats=True)
+    assert st.term_updates == 31 * 100_000_000
+    assert np.isfinite(lay.coords).all()
+    s = O.layout_stress(oracle_graph(g), 2, lay.coords, 100000)
+    c0 = S.default_layout_init(g, 2, p.seed)
+    s_init = O.layout_stress(oracle_graph(g), 2, c0, 100000)
+    assert s < 0.05 and s < 0.1 * s_init, (s_init, s)
+    # both ends of a node end up one node length apart
+    c = lay.coords.reshape(-1, 2, 2)
+    d = np.sqrt(((c[:, 0, :] - c[:, 1, :]) ** 2).sum(axis=1))
+    assert np.median(np.abs(d - g.node_len)) < 0.05
+
+
+def test_c5_scale_10m_nodes_100m_steps():
+    """BASELINE configs[4] on ONE GPU (size check): 10M nodes / 1024 paths / 1e8 steps."""
+    g = G.synth_windows(10_000_000, 1024, 97_656, 3)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 4
+    rc, x, st = hip.path_linear_sgd_raw(g, p)
+    assert rc == 0 and st.term_updates == 5 * g.n_steps and np.isfinite(x).all()
