@@ -154,6 +154,7 @@ struct gfs_ctx {
     uint64_t n_nodes = 0, n_steps = 0, n_paths = 0;
     uint32_t max_path_steps = 0;
     bool valid_paths = false;
+    std::vector<uint32_t> path_counts;
     // device mirror of PathIndex
     uint4 *d_step_rec = nullptr;
     uint4 *d_path_rec = nullptr;
@@ -171,6 +172,7 @@ struct gfs_ctx {
     gfs_term *d_trace = nullptr; uint32_t *d_trace_cnt = nullptr;
     uint64_t n_streams = 0, quota_total = 0;
     uint32_t block = 256;
+    uint32_t bundle = 1;               // lanes per sampling bundle actually used (1 = reference streams)
     bool lds_tables = true, atomic_loads = true;
     size_t lds_bytes = 0;
     // timing
@@ -281,10 +283,25 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     if (c->quota_total / T + 1 > 0xFFFFFFFFull) return fail(GFS_E_UNSUPPORTED, "per-stream quota exceeds 2^32");
     if (c->cfg.attempt_factor == 0) c->cfg.attempt_factor = 64;
     if (c->cfg.attempt_factor > 0xFFFFFFFFull) return fail(GFS_E_ARG, "attempt_factor too large");
-    {
+    {   // sampling bundle: 0 = auto, 1 = reference streams, 4..64 explicit (sgd_device.h)
         uint32_t b = (c->cfg.flags >> 16) & 0xFFu;
-        if (b > 1 && (T % 64 != 0 || (b != 4 && b != 8 && b != 16 && b != 64)))
-            return fail(GFS_E_ARG, "bundled sampling needs n_streams % 64 == 0 and a bundle of 4, 8, 16 or 64");
+        if (b > 1 && (T % 64 != 0 || dims != 0 || (b != 4 && b != 8 && b != 16 && b != 32 && b != 64)))
+            return fail(GFS_E_ARG, "bundled sampling needs the 1D path, n_streams % 64 == 0 and a bundle of 4, 8, 16, 32 or 64");
+        if (b == 0) {
+            // auto: the widest bundle that still leaves >= 65536 independent bundle draws per
+            // iteration and has >= 95 % of the steps in paths of at least 4*B steps.  Small graphs
+            // (and the nD path) therefore run reference streams.
+            b = 1;
+            if (dims == 0 && T % 64 == 0) {
+                for (uint32_t cand : {64u, 32u, 16u, 8u, 4u}) {
+                    if (c->quota_total / cand < 65536) continue;
+                    uint64_t long_steps = 0;
+                    for (uint32_t cnt : c->path_counts) if (cnt >= 4 * cand) long_steps += cnt;
+                    if ((double)long_steps >= 0.95 * (double)c->n_steps) { b = cand; break; }
+                }
+            }
+        }
+        c->bundle = b;
     }
     c->atomic_loads = !(c->cfg.flags & GFS_F_PLAIN_LOADS);
     size_t lds = (size_t)c->n_paths * sizeof(uint4) + (size_t)c->zlen_staged * 8;
@@ -370,6 +387,7 @@ int gfs_ctx_create(const gfs_graph_view *g, int device, gfs_ctx **out) {
         prec[p].x = (uint32_t)b; prec[p].y = cnt;
         prec[p].z = cnt ? (uint32_t)(0u - cnt) % cnt : 0u; prec[p].w = 0;
         plen[p] = position;
+        c->path_counts.push_back(cnt);
         if (cnt > 1) c->valid_paths = true;                               // sgd.rs:250-256
         c->max_path_steps = std::max(c->max_path_steps, cnt);
     }
@@ -470,7 +488,7 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
     a.dbg = (c->cfg.flags >> 8) & 0xFFu;
-    a.bundle = (c->cfg.flags >> 16) & 0xFFu;      // EXPERIMENTAL: GFS_F_BUNDLE(n)
+    a.bundle = c->bundle;
     iter_consts(c, k, a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
     if (c->events_used == c->events.size()) {
@@ -520,7 +538,7 @@ int gfs_ctx_stats(gfs_ctx *c, gfs_stats *out) {
     unsigned long long cnt[2] = {0, 0};
     HIPCHK(hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
     out->term_updates = cnt[0]; out->attempts = cnt[1];
-    out->iterations = c->iterations; out->n_streams = c->n_streams;
+    out->iterations = c->iterations; out->n_streams = c->n_streams; out->bundle = c->bundle;
     double ms = 0.0;
     for (size_t k = 0; k < c->events_used; ++k) {
         float t = 0.f;

@@ -18,12 +18,14 @@ struct Args {
     size_t iter_max = 100, threads = 1, dimensions = 2, layout_iter = 30;
     unsigned verbose = 1;
     uint64_t streams = 0; uint32_t flags = 0;      // HIP launch shape (extra, not in the reference)
+    unsigned bundle = 0;                           // 0 = auto, 1 = reference streams, 4..64
 };
 
 static void usage() {
     std::cerr <<
         "Usage: gfasort_hip -i <in.gfa> -o <out.gfa> [-p PIPELINE] [--iter-max N] [-t N] [-v N]\n"
         "                   [--dimensions D] [--layout-out FILE] [--layout-iter N] [--streams N]\n"
+        "                   [--bundle auto|1|4|8|16|32|64]   (sampling bundle; 1 = reference streams)\n"
         "Pipeline characters: Y = path-guided SGD sort, L = nD layout (HIP engine).\n"
         "g, s, S, u exist in the reference but are not part of this build.\n";
 }
@@ -43,6 +45,7 @@ static bool parse_args(int argc, char **argv, Args &a) {
         else if (f == "--layout-out") { if (!(v = need(i))) return false; a.layout_out = v; }
         else if (f == "--layout-iter") { if (!(v = need(i))) return false; a.layout_iter = std::stoull(v); }
         else if (f == "--streams") { if (!(v = need(i))) return false; a.streams = std::stoull(v); }
+        else if (f == "--bundle") { if (!(v = need(i))) return false; a.bundle = std::string(v) == "auto" ? 0u : (unsigned)std::stoul(v); }
         else if (f == "--hip-flags") { if (!(v = need(i))) return false; a.flags = (uint32_t)std::stoul(v); }
         else if (f == "-h" || f == "--help") { usage(); exit(0); }
         else { std::cerr << "error: unexpected argument '" << f << "'\n"; return false; }
@@ -95,7 +98,7 @@ int main(int argc, char **argv) {
     LayoutSGDParams layout_params = LayoutSGDParams::from_graph(graph, args.dimensions, args.threads);   // :227-229
     layout_params.iter_max = args.layout_iter;
     layout_params.progress = args.verbose >= 2;
-    HipOptions opt; opt.cfg.n_streams = args.streams; opt.cfg.flags = args.flags;
+    HipOptions opt; opt.cfg.n_streams = args.streams; opt.cfg.flags = args.flags | GFS_F_BUNDLE(args.bundle);
 
     bool have_layout = false;
     Layout layout;
@@ -120,7 +123,7 @@ int main(int argc, char **argv) {
             }
             if (args.verbose >= 1 && st.iterations)
                 std::cerr << "[gfasort_hip] " << st.term_updates << " term updates in " << st.iterations << " iterations on "
-                          << st.n_streams << " streams; kernels " << st.kernel_ms << " ms ("
+                          << st.n_streams << " streams (bundle " << st.bundle << "); kernels " << st.kernel_ms << " ms ("
                           << (st.kernel_ms > 0 ? (double)st.term_updates / st.kernel_ms / 1e6 : 0.0) << " G updates/s), call "
                           << st.total_ms << " ms\n";
         }

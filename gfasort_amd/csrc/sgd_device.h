@@ -159,70 +159,80 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
     return true;
 }
 
-// Bundled sampler (EXPERIMENTAL): B adjacent lanes share ONE draw of (step a0, Zipf/uniform,
-// direction, jump) made by the bundle's first lane from its own stream; lane l of the bundle
-// uses rank_a = (rank_a0 + l) mod cnt and the same signed jump (Zipf branch, clamped to the
-// path like sgd.rs:474,489) or rank_b = (rank_b0 + l) mod cnt (uniform branch).  Every lane's
-// term keeps the reference's marginal distribution up to path-end effects of O(B/cnt); what
-// changes is the correlation between concurrent terms, which buys hardware coalescing of the
-// record loads, position loads and atomics (B consecutive steps = 16*B contiguous bytes).
-template <bool LDS_TABLES, int B>
+// ------------------------------------------------------------------------------------------
+// Bundled sampler ("run sampling", GFS_F_BUNDLE(B)): B adjacent lanes form a bundle.  The
+// bundle's first lane (the leader) is an ordinary reference stream: it draws step a0, the
+// Zipf/uniform decision, the direction and the jump exactly as sgd.rs:444-495 does.  Lane l of
+// the bundle (a satellite) takes the step l places further along the path (wrapping to the path
+// start) and the SAME signed jump:  rank_a = (rank_a0 + l) mod cnt,  rank_b = rank_a + shift.
+//   * a satellite whose rank_b falls outside the path is rejected (never clamped: clamping
+//     would pile several lanes onto the path's last step);
+//   * when |shift| < B the bundle's terms would chain through shared nodes (a_{l+z} = b_l);
+//     only lanes with floor(l/z) even act, which makes the acting terms node-disjoint;
+//   * paths shorter than 2B steps are handled by the leader alone.
+// Every acting lane's term has the reference's marginal distribution up to path-end effects of
+// O(B/cnt); what changes is the correlation BETWEEN concurrent terms.  The pay-off is in the
+// memory system: B consecutive steps are 16*B contiguous record bytes and (for a locally sorted
+// graph) B neighbouring position words, so record loads, position loads and the f64 atomics of
+// a bundle coalesce into a few 64-B requests instead of B scattered ones.
+// ------------------------------------------------------------------------------------------
+template <int B>
 __device__ __forceinline__ bool sample_pair_bundled(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
                                                     Rng &rng, uint4 &ra, uint4 &rb, uint32_t &sa, uint32_t &sb,
-                                                    uint32_t &cnt_out, uint32_t &path_out) {
+                                                    uint32_t &first_out, uint32_t &cnt_out, uint32_t &path_out) {
     const int lane = threadIdx.x & 63;
     const int sub = lane & (B - 1);
     const int lead = lane & ~(B - 1);
-    uint32_t first = 0, cnt = 0, rank_a = 0, rank_b = 0, path = 0, zipf = 0, okl = 0;
+    uint32_t s0 = 0;
+    if (sub == 0) s0 = rng.uniform32(a.n_steps, a.steps_thresh);                       // sgd.rs:444 (leader)
+    s0 = __shfl(s0, lead, 64);
+    // speculative, coalesced load of the bundle's a-records (valid unless the run leaves the path)
+    uint32_t s_spec = s0 + (uint32_t)sub;
+    if (s_spec >= a.n_steps) s_spec = a.n_steps - 1u;
+    ra = a.step_rec[s_spec];
+    const uint32_t path = __shfl(ra.y, lead, 64) & 0x7FFFFFFFu;                        // :445
+    const uint4 pr = path_tab[path];
+    const uint32_t first = pr.x, cnt = pr.y;                                           // :446
+    if (cnt == 1u) return false;                                                       // :448 (whole bundle)
+    const uint32_t rank_a0 = s0 - first;                                               // :452
+    uint32_t rank_b0 = rank_a0;
     if (sub == 0) {
-        uint32_t step_idx = rng.uniform32(a.n_steps, a.steps_thresh);
-        uint4 r0 = a.step_rec[step_idx];
-        path = r0.y & 0x7FFFFFFFu;
-        uint4 pr = path_tab[path];
-        first = pr.x; cnt = pr.y;
-        if (cnt != 1u) {
-            okl = 1;
-            rank_a = step_idx - first;
-            rank_b = rank_a;
-            if (a.it.cooling || rng.flip() == 1u) {
-                zipf = 1;
-                bool back = false, fwd = false;
-                if (rank_a > 0u && (rng.flip() == 1u || rank_a == cnt - 1u)) back = true;
-                else if (rank_a < cnt - 1u) fwd = true;
-                if (back || fwd) {
-                    uint32_t room = back ? rank_a : (cnt - rank_a - 1u);
-                    uint32_t jump = a.space < room ? a.space : room;
-                    double zeta = zeta_tab[space_index(a, jump)];
-                    uint32_t z = dirty_zipf(a.it, jump, zeta, rng.f64());
-                    if (back) rank_b = rank_a >= z ? rank_a - z : 0u;
-                    else { uint64_t t = (uint64_t)rank_a + z; rank_b = t < cnt - 1u ? (uint32_t)t : cnt - 1u; }
-                }
-            } else {
-                rank_b = rng.uniform32(cnt, pr.z);
+        if (a.it.cooling || rng.flip() == 1u) {                                        // :456
+            bool back = false, fwd = false;
+            if (rank_a0 > 0u && (rng.flip() == 1u || rank_a0 == cnt - 1u)) back = true;  // :460
+            else if (rank_a0 < cnt - 1u) fwd = true;                                   // :475
+            if (back || fwd) {
+                uint32_t room = back ? rank_a0 : (cnt - rank_a0 - 1u);
+                uint32_t jump = a.space < room ? a.space : room;                       // :462,477
+                double zeta = zeta_tab[space_index(a, jump)];
+                uint32_t z = dirty_zipf(a.it, jump, zeta, rng.f64());                  // :472-473
+                if (back) rank_b0 = rank_a0 >= z ? rank_a0 - z : 0u;                   // :474
+                else { uint64_t t = (uint64_t)rank_a0 + z; rank_b0 = t < cnt - 1u ? (uint32_t)t : cnt - 1u; }  // :489
             }
-        }
-    }
-    okl = __shfl(okl, lead, 64);
-    if (!okl) return false;
-    first = __shfl(first, lead, 64); cnt = __shfl(cnt, lead, 64); path = __shfl(path, lead, 64);
-    rank_a = __shfl(rank_a, lead, 64); rank_b = __shfl(rank_b, lead, 64); zipf = __shfl(zipf, lead, 64);
-    uint32_t ra_l, rb_l;
-    if (cnt < 2u * B) {                 // short path: only the bundle leader acts (keeps tiny graphs exact)
-        if (sub != 0) return false;
-        ra_l = rank_a; rb_l = rank_b;
-    } else {
-        ra_l = rank_a + (uint32_t)sub; if (ra_l >= cnt) ra_l -= cnt;
-        if (zipf) {
-            int64_t t = (int64_t)ra_l + ((int64_t)rank_b - (int64_t)rank_a);
-            rb_l = t < 0 ? 0u : (t > (int64_t)cnt - 1 ? cnt - 1u : (uint32_t)t);
         } else {
-            rb_l = rank_b + (uint32_t)sub; if (rb_l >= cnt) rb_l -= cnt;
+            rank_b0 = rng.uniform32(cnt, pr.z);                                        // :493-494
         }
     }
-    if (ra_l == rb_l) return false;
-    sa = first + ra_l; sb = first + rb_l;
-    ra = a.step_rec[sa]; rb = a.step_rec[sb];
-    cnt_out = cnt; path_out = path;
+    rank_b0 = __shfl(rank_b0, lead, 64);
+    if (rank_b0 == rank_a0) return false;                                              // :497 (leader's term; bundle follows)
+    uint32_t ra_l = rank_a0, rb_l = rank_b0;
+    if (sub != 0) {
+        if (cnt < 2u * B) return false;                                                // short path: leader only
+        const int64_t shift = (int64_t)rank_b0 - (int64_t)rank_a0;
+        const uint32_t z = (uint32_t)(shift < 0 ? -shift : shift);
+        if (z < (uint32_t)B && ((((uint32_t)sub) / z) & 1u)) return false;             // node-disjoint lanes only
+        ra_l = rank_a0 + (uint32_t)sub;
+        const bool wrapped = ra_l >= cnt;
+        if (wrapped) ra_l -= cnt;
+        const int64_t t = (int64_t)ra_l + shift;
+        if (t < 0 || t > (int64_t)cnt - 1) return false;                               // outside the path: reject
+        rb_l = (uint32_t)t;
+        if (wrapped) ra = a.step_rec[first + ra_l];                                    // rare: reload
+    }
+    sa = first + ra_l;                                                                 // :502
+    sb = first + rb_l;                                                                 // :503
+    rb = a.step_rec[sb];
+    first_out = first; cnt_out = cnt; path_out = path;
     return true;
 }
 

@@ -63,7 +63,7 @@ __device__ __forceinline__ void flush_counters(const KArgs &a, uint32_t done, ui
 // ------------------------------------------------------------------------------------------
 // K1: 1D
 // ------------------------------------------------------------------------------------------
-template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE, int BUNDLE>
+template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __global__ void sgd1d_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
@@ -81,17 +81,10 @@ __global__ void sgd1d_kernel(const KArgs a) {
         const uint32_t max_att = max_att64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_att64;
         uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
         double *x = a.x;
-        for (;;) {
-            bool want = done < quota && att < max_att;
-            if (BUNDLE == 1) { if (!want) break; }
-            else if (__ballot(want) == 0ull) break;                 // bundle mode: wave-uniform trip count
-            uint4 ra, rb; uint32_t sa, sb, cnt, path;
-            bool got;
-            if (BUNDLE == 1) got = sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path);
-            else got = sample_pair_bundled<LDS_TABLES, BUNDLE>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path);
-            if (!want) continue;
+        while (done < quota && att < max_att) {
             ++att;
-            if (!got) continue;
+            uint4 ra, rb; uint32_t sa, sb, cnt, path;
+            if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) continue;
             double term_dist = fabs(rec_pos(ra) - rec_pos(rb));                        // sgd.rs:513
             if (term_dist == 0.0) continue;                                            // :514
             double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                       // :518-520
@@ -122,6 +115,78 @@ __global__ void sgd1d_kernel(const KArgs a) {
         a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;
         if (TRACE) a.trace_cnt[tid] = ntr;
     }
+    flush_counters(a, done, att);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1b: 1D with bundled sampling (sgd_device.h, sample_pair_bundled).  The quota is per WAVE:
+// a wave keeps taking trips until its lanes have together performed the wave's share of the
+// iteration's updates; in the last trip the acting lanes are cut off by their rank among the
+// valid lanes, so an iteration still performs exactly its number of updates.  Only bundle
+// leaders consume random numbers in 1D, so only their RNG state is loaded and stored.
+// ------------------------------------------------------------------------------------------
+template <int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__global__ void sgd1d_bundle_kernel(const KArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
+
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;       // n_streams % 64 == 0 (host-checked)
+    if (tid >= a.n_streams) return;                                   // whole waves only
+    const int lane = threadIdx.x & 63;
+    const bool leader = (lane & (B - 1)) == 0;
+    const uint64_t T = a.n_streams;
+    Rng rng{0, 0, 0, 0};
+    if (leader) { rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid]; }
+    // wave quota = sum of its 64 lanes' per-stream quotas
+    const uint32_t wave_first = tid & ~63u;
+    uint64_t wave_quota = (uint64_t)a.quota_base * 64u;
+    if (wave_first < a.quota_rem) wave_quota += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
+    const uint64_t max_trips = (uint64_t)a.attempt_factor * (wave_quota / 64u + 1u) + 1024u;
+    uint64_t wave_done = 0, trips = 0;
+    uint32_t done = 0, att = 0;
+    uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
+    double *x = a.x;
+    while (wave_done < wave_quota && trips < max_trips) {
+        ++trips; ++att;
+        uint4 ra, rb; uint32_t sa, sb, first, cnt, path;
+        bool valid = sample_pair_bundled<B>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, first, cnt, path);
+        double term_dist = 0.0;
+        uint32_t i = 0, j = 0;
+        if (valid) {
+            term_dist = fabs(rec_pos(ra) - rec_pos(rb));                               // sgd.rs:513
+            i = ra.x; j = rb.x;
+            valid = term_dist != 0.0 && i != 0xFFFFFFFFu && j != 0xFFFFFFFFu;          // :514, :525-538
+        }
+        const unsigned long long vmask = __ballot(valid);
+        const uint64_t remaining = wave_quota - wave_done;
+        const uint32_t nvalid = (uint32_t)__popcll(vmask);
+        if (valid && nvalid > remaining) {
+            const uint32_t rank = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull));
+            valid = rank < remaining;
+        }
+        wave_done += nvalid < remaining ? nvalid : remaining;
+        if (!valid) continue;
+        double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                           // :518-520
+        double dx = load_pos<ATOMIC_LOADS>(x + i) - load_pos<ATOMIC_LOADS>(x + j);     // :541-543
+        if (dx == 0.0) dx = 1e-9;                                                      // :546-548
+        double mag = fabs(dx);                                                         // :551
+        double delta = mu * (mag - term_dist) / 2.0;                                   // :552
+        double r = delta / mag;                                                        // :570
+        double r_x = r * dx;                                                           // :571
+        add_pos(x + i, -r_x);                                                          // :575
+        add_pos(x + j, r_x);                                                           // :576
+        ++done;                                                                        // :579
+        if (TRACE) {
+            if (ntr < a.trace_per_stream) {
+                TraceTerm *t = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                t->i = i; t->j = j; t->d = term_dist;
+                ++ntr;
+            }
+        }
+    }
+    if (leader) { a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3; }
+    if (TRACE) a.trace_cnt[tid] = ntr;
     flush_counters(a, done, att);
 }
 
@@ -209,28 +274,39 @@ __global__ void sgdnd_kernel(const KArgs a) {
 }
 
 // ---- host-side launch dispatch -------------------------------------------------------------
-template <bool L, bool A, int B>
+template <bool L, bool A>
 static hipError_t launch_1d_t(const KArgs &a, bool trace, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (trace) hipLaunchKernelGGL((sgd1d_kernel<L, A, true, B>), grid, block, lds, st, a);
-    else       hipLaunchKernelGGL((sgd1d_kernel<L, A, false, B>), grid, block, lds, st, a);
+    if (trace) hipLaunchKernelGGL((sgd1d_kernel<L, A, true>), grid, block, lds, st, a);
+    else       hipLaunchKernelGGL((sgd1d_kernel<L, A, false>), grid, block, lds, st, a);
+    return hipGetLastError();
+}
+template <int B, bool L, bool A>
+static hipError_t launch_1db_t(const KArgs &a, bool trace, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (trace) hipLaunchKernelGGL((sgd1d_bundle_kernel<B, L, A, true>), grid, block, lds, st, a);
+    else       hipLaunchKernelGGL((sgd1d_bundle_kernel<B, L, A, false>), grid, block, lds, st, a);
     return hipGetLastError();
 }
 template <int B>
-static hipError_t launch_1d_b(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
-                              dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (lds_tables) return atomic_loads ? launch_1d_t<true, true, B>(a, trace, grid, block, lds, st)
-                                        : launch_1d_t<true, false, B>(a, trace, grid, block, lds, st);
-    return atomic_loads ? launch_1d_t<false, true, B>(a, trace, grid, block, 0, st)
-                        : launch_1d_t<false, false, B>(a, trace, grid, block, 0, st);
+static hipError_t launch_1db(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                             dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (lds_tables) return atomic_loads ? launch_1db_t<B, true, true>(a, trace, grid, block, lds, st)
+                                        : launch_1db_t<B, true, false>(a, trace, grid, block, lds, st);
+    return atomic_loads ? launch_1db_t<B, false, true>(a, trace, grid, block, 0, st)
+                        : launch_1db_t<B, false, false>(a, trace, grid, block, 0, st);
 }
 hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
                      dim3 grid, dim3 block, size_t lds, hipStream_t st) {
     switch (a.bundle) {
-        case 0: case 1: return launch_1d_b<1>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
-        case 4:  return launch_1d_b<4>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
-        case 8:  return launch_1d_b<8>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
-        case 16: return launch_1d_b<16>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
-        case 64: return launch_1d_b<64>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 0: case 1:
+            if (lds_tables) return atomic_loads ? launch_1d_t<true, true>(a, trace, grid, block, lds, st)
+                                                : launch_1d_t<true, false>(a, trace, grid, block, lds, st);
+            return atomic_loads ? launch_1d_t<false, true>(a, trace, grid, block, 0, st)
+                                : launch_1d_t<false, false>(a, trace, grid, block, 0, st);
+        case 4:  return launch_1db<4>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 8:  return launch_1db<8>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 16: return launch_1db<16>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 32: return launch_1db<32>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 64: return launch_1db<64>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
         default: return hipErrorInvalidValue;
     }
 }

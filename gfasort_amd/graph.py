@@ -231,6 +231,45 @@ def synth_windows(n_nodes: int, n_paths: int, window: int, seed: int, shuffle: b
     )
 
 
+def synth_bubbles(n_sites: int, n_haplotypes: int, seed: int, shuffle: bool = True) -> FlatGraph:
+    """Pangenome-like graph: a backbone of n_sites "sites"; every 4th site is a biallelic bubble
+    (two alternative nodes), every 16th site carries an optional insertion node, the others are a
+    single shared node.  Each of n_haplotypes paths walks all sites choosing alleles at random
+    (SplitMix64(seed+2)).  Node ids follow site order (allele 0, allele 1, insertion); S lines
+    are block-shuffled like the other generators.  All steps forward."""
+    site = np.arange(n_sites)
+    is_bub = (site % 4 == 1)
+    has_ins = (site % 16 == 7)
+    n_per_site = 1 + is_bub.astype(np.int64) + has_ins.astype(np.int64)
+    first_id0 = np.concatenate([[0], np.cumsum(n_per_site)])[:-1]            # 0-based id of the site's allele 0
+    n_nodes = int(n_per_site.sum())
+    lens_by_id = _node_lengths(n_nodes, seed)
+    order = _block_shuffled_order(n_nodes, seed + 1) if shuffle else np.arange(n_nodes, dtype=np.int64)
+    inv = np.empty(n_nodes, dtype=np.int64)
+    inv[order] = np.arange(n_nodes)
+    r = splitmix64_array(seed + 2, n_haplotypes * n_sites).reshape(n_haplotypes, n_sites)
+    allele = ((r >> np.uint64(13)) & np.uint64(1)).astype(np.int64) * is_bub[None, :]
+    take_ins = (((r >> np.uint64(29)) & np.uint64(3)) == 0) & has_ins[None, :]           # 25 % carry the insertion
+    steps, firsts = [], [0]
+    for h in range(n_haplotypes):
+        main = first_id0 + allele[h]
+        ins = first_id0 + 1 + is_bub.astype(np.int64)
+        seq = np.stack([main, np.where(take_ins[h], ins, -1)], axis=1).reshape(-1)
+        seq = seq[seq >= 0]
+        steps.append(seq)
+        firsts.append(firsts[-1] + seq.shape[0])
+    steps0 = np.concatenate(steps)
+    return FlatGraph(
+        node_len=lens_by_id[order].astype(np.uint32),
+        step_node=inv[steps0].astype(np.uint32),
+        step_is_rev=np.zeros(steps0.shape[0], dtype=np.uint8),
+        path_first_step=np.array(firsts, dtype=np.uint64),
+        node_ids=(order + 1).astype(np.uint64),
+        path_names=[f"h{h}" for h in range(n_haplotypes)],
+        step_node_id=(steps0 + 1).astype(np.uint64),
+    )
+
+
 def synth_chain(n_nodes: int, seed: int, shuffle: bool = True) -> FlatGraph:
     """`chain(N,seed)`: one path 1+,..,N+ over a linear chain; S lines block-shuffled."""
     return synth_windows(n_nodes, 1, n_nodes, seed, shuffle)

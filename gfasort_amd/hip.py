@@ -14,6 +14,11 @@ OK, NOTHING_TO_DO = 0, 1
 F_PLAIN_LOADS, F_NO_LDS_TABLES = 1, 2
 
 
+def F_BUNDLE(n):
+    """GFS_F_BUNDLE(n): 0 = auto, 1 = reference streams, 4..64 = explicit bundle width."""
+    return (int(n) & 0xFF) << 16
+
+
 class GfsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"gfasort_hip error {code}: {msg}")
@@ -47,7 +52,8 @@ class LaunchConfig(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("term_updates", C.c_uint64), ("attempts", C.c_uint64), ("iterations", C.c_uint64),
-                ("n_streams", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("n_streams", C.c_uint64), ("bundle", C.c_uint64), ("kernel_ms", C.c_double),
+                ("total_ms", C.c_double)]
 
 
 TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)

@@ -95,8 +95,13 @@ typedef struct gfs_launch_config {
 #define GFS_F_PLAIN_LOADS   1u        /* read positions with plain (L2-cacheable) loads instead
                                          of agent-scope relaxed atomic loads                 */
 #define GFS_F_NO_LDS_TABLES 2u        /* keep zeta/path tables in global memory              */
-#define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* EXPERIMENTAL: n in {4,8,16,64} adjacent lanes share
-                                         one sampled (step, jump) and take consecutive steps  */
+/* Sampling bundle (1D): n adjacent lanes share ONE sampled (step a, jump) drawn by the bundle's
+ * first lane — an ordinary reference stream — and take n consecutive steps of the path with the
+ * same signed jump, so that record loads, position loads and atomics of a bundle coalesce into a
+ * few 64-B requests (gfasort_amd/csrc/sgd_device.h).  n = 1: reference streams, every lane is a
+ * reference worker thread.  n = 0 (default): the library picks by graph size — 1 for small
+ * graphs, up to 64 when an iteration still has >= 65536 independent bundle draws.            */
+#define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* n in {0 = auto, 1, 4, 8, 16, 32, 64} */
 #define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
 #define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
 
@@ -105,6 +110,7 @@ typedef struct gfs_stats {
     uint64_t attempts;                /* loop trips including `continue`s                    */
     uint64_t iterations;              /* batches launched                                    */
     uint64_t n_streams;               /* streams actually used                               */
+    uint64_t bundle;                  /* lanes per sampling bundle actually used (1 = reference streams) */
     double   kernel_ms;               /* sum of SGD kernel durations (HIP events)            */
     double   total_ms;                /* wall time inside the call (one-shot) / run          */
 } gfs_stats;

@@ -512,7 +512,7 @@ struct gfo_state {
     gfo_params p;
     double *etas, *zetas;
     zipf_env z;
-    uint64_t T, D, quota_total, attempt_factor;
+    uint64_t T, D, quota_total, attempt_factor, bundle;
     uint64_t *rng, *done, *att, *ntr;
     gfo_term *trace; uint64_t trace_per_stream;
     uint64_t total_upd, total_att, iterations;
@@ -535,7 +535,7 @@ int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas
     gfo_state *s = (gfo_state *)calloc(1, sizeof *s);
     if (!s) return -2;
     if (pidx_build(g, 1, &s->pi)) { gfo_state_destroy(s); return -2; }
-    s->p = *p; s->T = n_streams; s->D = dims;
+    s->p = *p; s->T = n_streams; s->D = dims; s->bundle = 1;
     s->quota_total = quota_total ? quota_total : p->min_term_updates;
     s->attempt_factor = attempt_factor ? attempt_factor : 64;
     s->etas = (double *)malloc((p->iter_max + 1) * 8);
@@ -553,6 +553,103 @@ int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Bundled ("run") sampling — NOT in the reference.  This mirrors, decision for decision, the
+ * product's coalesced sampler (gfasort_amd/csrc/sgd_device.h sample_pair_bundled and the
+ * wave-level quota of sgd1d_bundle_kernel) so that its random-number consumption and the
+ * terms it emits can be checked bit for bit.  The bundle leader is an ordinary reference
+ * stream (sgd.rs:444-495); satellites take consecutive steps with the leader's signed jump.
+ * Updates of one trip are applied here in lane order; the GPU applies them concurrently.
+ * ---------------------------------------------------------------------------------------- */
+int gfo_state_set_bundle(gfo_state *s, uint64_t bundle) {
+    if (!s) return -1;
+    if (bundle == 0) bundle = 1;
+    if (bundle != 1 && (s->T % 64 != 0 || (bundle != 4 && bundle != 8 && bundle != 16 && bundle != 32 && bundle != 64)))
+        return -1;
+    if (bundle != 1 && s->D != 0) return -1;          /* 1D only, like the product */
+    s->bundle = bundle;
+    return 0;
+}
+
+static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
+    const uint64_t T = s->T, B = s->bundle;
+    const pidx *pi = &s->pi;
+    iter_state it; iter_consts(&s->p, s->etas, k, &it);
+    const uint64_t base = s->quota_total / T, rem = s->quota_total % T;
+    for (uint64_t w = 0; w < T / 64; w++) {
+        const uint64_t wave_first = w * 64;
+        uint64_t wave_quota = base * 64;
+        if (wave_first < rem) wave_quota += (rem - wave_first) < 64 ? (rem - wave_first) : 64;
+        const uint64_t max_trips = s->attempt_factor * (wave_quota / 64 + 1) + 1024;
+        uint64_t wave_done = 0, trips = 0;
+        while (wave_done < wave_quota && trips < max_trips) {
+            trips++;
+            int valid[64]; uint64_t sa[64], sb[64];
+            for (uint64_t b0 = 0; b0 < 64; b0 += B) {
+                uint64_t *rng = s->rng + 4 * (wave_first + b0);
+                for (uint64_t l = 0; l < B; l++) valid[b0 + l] = 0;
+                uint64_t s0 = uniform_usize(rng, pi->n_steps);                         /* :444 (leader) */
+                uint64_t path = pi->rec[s0].path_rev & 0x7FFFFFFFu;
+                uint64_t first = pi->paths[path].first_step, cnt = pi->paths[path].step_count;
+                if (cnt == 1) continue;                                                /* :448 */
+                uint64_t rank_a0 = s0 - first, rank_b0 = rank_a0;
+                if (it.cooling || flip(rng) == 1) {                                    /* :456 */
+                    if (rank_a0 > 0 && (flip(rng) == 1 || rank_a0 == cnt - 1)) {      /* :460 */
+                        uint64_t jump = s->z.space < rank_a0 ? s->z.space : rank_a0;
+                        double z2 = 1.0 + fpp(0.5, it.theta);
+                        uint64_t zi = gfo_dirty_zipfian(1, jump, it.theta, s->z.zetas[space_index(&s->z, jump)], z2, random_f64(rng));
+                        rank_b0 = rank_a0 >= zi ? rank_a0 - zi : 0;
+                    } else if (rank_a0 < cnt - 1) {
+                        uint64_t room = cnt - rank_a0 - 1;
+                        uint64_t jump = s->z.space < room ? s->z.space : room;
+                        double z2 = 1.0 + fpp(0.5, it.theta);
+                        uint64_t zi = gfo_dirty_zipfian(1, jump, it.theta, s->z.zetas[space_index(&s->z, jump)], z2, random_f64(rng));
+                        uint64_t rb = rank_a0 + zi;
+                        rank_b0 = rb < cnt - 1 ? rb : cnt - 1;
+                    }
+                } else {
+                    rank_b0 = uniform_usize(rng, cnt);                                 /* :493-494 */
+                }
+                if (rank_b0 == rank_a0) continue;                                      /* :497 */
+                const int64_t shift = (int64_t)rank_b0 - (int64_t)rank_a0;
+                const uint64_t zabs = (uint64_t)(shift < 0 ? -shift : shift);
+                valid[b0] = 1; sa[b0] = first + rank_a0; sb[b0] = first + rank_b0;     /* leader */
+                for (uint64_t l = 1; l < B; l++) {                                     /* satellites */
+                    if (cnt < 2 * B) break;
+                    if (zabs < B && ((l / zabs) & 1)) continue;
+                    uint64_t ra = rank_a0 + l;
+                    if (ra >= cnt) ra -= cnt;
+                    int64_t t = (int64_t)ra + shift;
+                    if (t < 0 || t > (int64_t)cnt - 1) continue;
+                    valid[b0 + l] = 1; sa[b0 + l] = first + ra; sb[b0 + l] = first + (uint64_t)t;
+                }
+            }
+            uint64_t nvalid = 0;
+            for (int l = 0; l < 64; l++) {
+                if (!valid[l]) continue;
+                double td = fabs((double)pi->rec[sa[l]].pos - (double)pi->rec[sb[l]].pos);
+                if (td == 0.0 || pi->rec[sa[l]].node == GFO_NO_NODE || pi->rec[sb[l]].node == GFO_NO_NODE) valid[l] = 0;
+                else nvalid++;
+            }
+            const uint64_t remaining = wave_quota - wave_done;
+            uint64_t rank = 0;
+            for (int l = 0; l < 64; l++) {
+                s->att[wave_first + l]++;
+                if (!valid[l]) continue;
+                if (rank++ >= remaining) continue;
+                gfo_term tr;
+                int ok = term_1d(pi, 1, &it, sa[l], sb[l], x, 0, NULL, &tr);
+                (void)ok;
+                uint64_t t = wave_first + l;
+                s->done[t]++;
+                if (s->trace && s->ntr[t] < s->trace_per_stream) s->trace[t * s->trace_per_stream + s->ntr[t]++] = tr;
+            }
+            wave_done += nvalid < remaining ? nvalid : remaining;
+        }
+    }
+    return 0;
+}
+
 /* One batch: iteration k uses etas[k]; streams advance round-robin, one attempt each. */
 int gfo_state_run_iteration(gfo_state *s, uint64_t k, double *x) {
     if (!s || k > s->p.iter_max) return -1;
@@ -561,6 +658,13 @@ int gfo_state_run_iteration(gfo_state *s, uint64_t k, double *x) {
     iter_state it; iter_consts(&s->p, s->etas, k, &it);
     uint64_t base = s->quota_total / T, rem = s->quota_total % T;
     memset(s->done, 0, T * 8); memset(s->att, 0, T * 8);
+    if (s->bundle > 1) {
+        run_iteration_bundled(s, k, x);
+        for (uint64_t t = 0; t < T; t++) { s->total_upd += s->done[t]; s->total_att += s->att[t]; }
+        s->iterations++;
+        s->seconds += now_s() - t0;
+        return 0;
+    }
     for (;;) {
         int active = 0;
         for (uint64_t t = 0; t < T; t++) {

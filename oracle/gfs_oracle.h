@@ -118,6 +118,9 @@ typedef struct gfo_state gfo_state;
 int  gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas, const double *zetas,
                       uint64_t dims, uint64_t n_streams, uint64_t stream_base, uint64_t quota_total,
                       uint64_t attempt_factor, gfo_term *trace, uint64_t trace_per_stream, gfo_state **out);
+/* bundle > 1: mirror of the product's bundled ("run") sampler — NOT a reference mode; 1D only,
+ * n_streams % 64 == 0, bundle in {4,8,16,32,64}.  See gfs_oracle.c. */
+int  gfo_state_set_bundle(gfo_state *s, uint64_t bundle);
 int  gfo_state_run_iteration(gfo_state *s, uint64_t k, double *x);
 void gfo_state_stats(const gfo_state *s, gfo_stats *st);
 void gfo_state_destroy(gfo_state *s);

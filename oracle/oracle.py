@@ -218,6 +218,47 @@ def sgd_nd_threads(g, p, coords, flat=0, max_seconds=0.0, etas=None, zts=None):
     return rc, st
 
 
+class State:
+    """Resumable deterministic run (gfo_state).  bundle > 1 mirrors the product's bundled sampler."""
+
+    def __init__(self, g, p, dims=0, n_streams=1, stream_base=0, quota_total=0, attempt_factor=64,
+                 trace_per_stream=0, bundle=1, etas=None, zts=None):
+        self.g, self.p = g, p
+        self.trace = np.zeros(n_streams * trace_per_stream, dtype=TERM_DTYPE) if trace_per_stream else None
+        self.h = C.c_void_p()
+        rc = lib().gfo_state_create(g.ref, C.byref(p), _ptr(etas), _ptr(zts), C.c_uint64(dims), C.c_uint64(n_streams),
+                                    C.c_uint64(stream_base), C.c_uint64(quota_total), C.c_uint64(attempt_factor),
+                                    _ptr(self.trace), C.c_uint64(trace_per_stream), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"gfo_state_create rc={rc}")
+        if bundle != 1 and lib().gfo_state_set_bundle(self.h, C.c_uint64(bundle)) != 0:
+            raise ValueError("bad bundle")
+        self.n_streams, self.trace_per_stream = n_streams, trace_per_stream
+
+    def run_iteration(self, k, x):
+        assert lib().gfo_state_run_iteration(self.h, C.c_uint64(k), _ptr(x)) == 0
+
+    def run(self, x):
+        for k in range(self.p.iter_max + 1):
+            self.run_iteration(k, x)
+
+    def stats(self):
+        st = GfoStats()
+        lib().gfo_state_stats(self.h, C.byref(st))
+        return st
+
+    def close(self):
+        if self.h:
+            lib().gfo_state_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def layout_stress(g, dims, coords, samples=10000):
     return lib().gfo_layout_stress(g.ref, dims, _ptr(np.ascontiguousarray(coords, dtype=np.float64)), samples)
 

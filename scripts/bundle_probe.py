@@ -31,7 +31,7 @@ def main():
         g = G.synth_windows(1_000_000, 64, 156_250, 2)
         p = P.YgsParams.from_graph(g, 0, 1).path_sgd
         p.iter_max = 200
-        for b in (1, 4, 8, 16, 64):
+        for b in (1, 4, 8, 16, 32, 64):
             x, st, dt = run(g, p, b)
             s, inv = quality(g, x)
             print(f"C3 bundle={b:2d}: {st.term_updates/ (st.kernel_ms*1e-3)/1e9:7.3f} G upd/s (kernel) wall {dt:.3f}s updates {st.term_updates} "
@@ -39,7 +39,7 @@ def main():
     if which in ("all", "c2"):
         g = G.synth_chain(100_000, 1)
         p = P.YgsParams.from_graph(g, 0, 1).path_sgd
-        for b in (1, 8, 64):
+        for b in (1, 8, 16, 64):
             x, st, dt = run(g, p, b)
             s, inv = quality(g, x)
             print(f"C2 bundle={b:2d}: {st.term_updates/ (st.kernel_ms*1e-3)/1e9:7.3f} G upd/s streams {st.n_streams} stress {s:.3e} inversions {inv}", flush=True)
@@ -48,7 +48,7 @@ def main():
         p = P.YgsParams.from_graph(g, 0, 1).path_sgd
         og = O.Graph(g.node_len, g.step_node, g.step_is_rev, g.path_first_step)
         print("DRB1 initial stress", O.stress_1d(og, O.init_positions(og), 200000))
-        for b in (1, 4, 8, 16, 64):
+        for b in (1, 4, 8, 16, 32, 64):
             res = []
             for seed in range(3):
                 p.seed = 9399220 + 1000 * seed

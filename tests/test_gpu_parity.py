@@ -208,14 +208,16 @@ def test_c2_chain_100k_sorts_exactly():
     assert _chain_order_ok(g, x)
 
 
-def test_c3_full_size_sorts_exactly_and_counts():
-    """BASELINE configs[2]: 1M nodes / 64 paths / 10M steps, -p Y --iter-max 200 => 2.01e9 updates."""
+@pytest.mark.parametrize("bundle,want_bundle", [(1, 1), (0, 64), (8, 8)])
+def test_c3_full_size_sorts_exactly_and_counts(bundle, want_bundle):
+    """BASELINE configs[2]: 1M nodes / 64 paths / 10M steps, -p Y --iter-max 200 => 2.01e9 updates.
+    bundle 1 = reference streams; 0 = the library's auto policy (64 lanes per bundle at this size)."""
     g = G.synth_windows(1_000_000, 64, 156_250, 2)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
     p.iter_max = 200
     assert (p.min_term_updates, p.eta_max) == (10_000_000, 156250.0 ** 2)
-    rc, x, st = hip.path_linear_sgd_raw(g, p)
-    assert rc == 0 and st.term_updates == 201 * 10_000_000 and st.iterations == 201
+    rc, x, st = hip.path_linear_sgd_raw(g, p, cfg=hip.make_config(flags=hip.F_BUNDLE(bundle)))
+    assert rc == 0 and st.term_updates == 201 * 10_000_000 and st.iterations == 201 and st.bundle == want_bundle
     assert np.isfinite(x).all() and _chain_order_ok(g, x)
     # sorted layout reproduces path distances: consecutive nodes are node_len apart
     order = hip.sort_order(x).astype(np.int64)
@@ -250,3 +252,79 @@ def test_c5_scale_10m_nodes_100m_steps():
     p.iter_max = 4
     rc, x, st = hip.path_linear_sgd_raw(g, p)
     assert rc == 0 and st.term_updates == 5 * g.n_steps and np.isfinite(x).all()
+
+
+# ---- bundled ("run") sampling: exact mirror check of the sampler, then quality ---------------------------
+@pytest.mark.parametrize("B", [4, 8, 16, 32, 64])
+def test_bundled_sampler_trace_matches_oracle_mirror(B):
+    """The bundled sampler's random-number consumption and emitted terms equal the oracle's mirror of
+    it bit for bit (leader = reference stream, satellites = consecutive steps, wave-level quota)."""
+    g = load("DRB1-3123.gfa")
+    p = _ygs(g, 6)
+    T, K = 512, 48
+    og, op = oracle_graph(g), oracle_params(p)
+    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B)
+    x_ref = O.init_positions(og)
+    st_o.run(x_ref)
+    so = st_o.stats()
+    ctx = hip.Context(g)
+    assert ctx.setup_1d(p, hip.make_config(n_streams=T, trace_per_stream=K, flags=hip.F_BUNDLE(B))) == 0
+    ctx.upload(hip.init_positions(g))
+    ctx.run()
+    tr, counts = ctx.trace()
+    hst = ctx.stats()
+    assert hst.bundle == B and hst.term_updates == so.term_updates == 7 * p.min_term_updates
+    assert hst.attempts == so.attempts
+    tr_ref = st_o.trace.reshape(T, K)
+    assert np.array_equal(tr["i"], tr_ref["i"]) and np.array_equal(tr["j"], tr_ref["j"])
+    assert np.array_equal(tr["d_ij"].view(np.uint64), tr_ref["d_ij"].view(np.uint64))
+    assert np.isfinite(ctx.download()).all()
+    ctx.close()
+
+
+def test_bundled_terms_are_node_disjoint_within_a_bundle():
+    """When |jump| < B only every other block of lanes acts: no node is touched twice by one bundle trip."""
+    g = G.synth_chain(5000, 3)
+    p = _ygs(g, 2)
+    T, K, B = 64, 200, 16
+    ctx = hip.Context(g)
+    ctx.setup_1d(p, hip.make_config(n_streams=T, trace_per_stream=K, flags=hip.F_BUNDLE(B)))
+    ctx.upload(hip.init_positions(g))
+    ctx.run_iteration(0)
+    tr, counts = ctx.trace()
+    ctx.close()
+    # terms of one trip of one bundle = k-th trace entry of the lanes that acted; on a chain the first
+    # trips are taken by all lanes while |jump| >= B, so compare entry 0 of each bundle
+    for b0 in range(0, T, B):
+        lanes = [l for l in range(b0, b0 + B) if counts[l] > 0]
+        first_terms = [(int(tr[l, 0]["i"]), int(tr[l, 0]["j"])) for l in lanes]
+        nodes = [n for t in first_terms for n in t]
+        assert len(nodes) == len(set(nodes)) or len(lanes) < B      # disjoint unless lanes were masked in trip 0
+
+
+def test_auto_bundle_policy():
+    g_small = load("DRB1-3123.gfa")
+    rc, x, st = hip.path_linear_sgd_raw(g_small, _ygs(g_small, 2))
+    assert st.bundle == 1                                            # small graph: reference streams
+    g_mid = G.synth_bubbles(20000, 16, 5)                            # 325k steps -> 4 lanes per bundle
+    rc, x, st = hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2))
+    assert st.bundle == 4
+    rc, x, st = hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2), cfg=hip.make_config(n_streams=1))
+    assert st.bundle == 1                                            # a single stream is always a reference stream
+    with pytest.raises(hip.GfsError):
+        hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2), cfg=hip.make_config(n_streams=100, flags=hip.F_BUNDLE(8)))
+
+
+@pytest.mark.parametrize("B", [16, 64])
+def test_bundled_quality_matches_reference_streams_on_bubble_graph(B):
+    """P2: pangenome-like graph (SNP bubbles + insertions, 16 haplotypes): sampled stress of the bundled
+    sampler within 10 % of reference streams at equal update counts."""
+    g = G.synth_bubbles(20000, 16, 5)
+    p = _ygs(g, 100)
+    og = oracle_graph(g)
+    s0 = O.stress_1d(og, O.init_positions(og), 100000)
+    rc, x1, st1 = hip.path_linear_sgd_raw(g, p, cfg=hip.make_config(flags=hip.F_BUNDLE(1)))
+    rc, xb, stb = hip.path_linear_sgd_raw(g, p, cfg=hip.make_config(flags=hip.F_BUNDLE(B)))
+    s1, sb = O.stress_1d(og, x1, 100000), O.stress_1d(og, xb, 100000)
+    assert st1.term_updates == stb.term_updates == 101 * p.min_term_updates
+    assert s1 < 0.05 * s0 and abs(sb - s1) < 0.10 * s1 + 1e-4, (s0, s1, sb)
