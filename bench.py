@@ -76,6 +76,32 @@ def cpu_baseline(g, p, seconds=12.0):
             "flat_variant_value": val_flat}
 
 
+def reference_streams_leg(g, p, device_index, args, steps=60):
+    """Same workload with GFS_F_BUNDLE(1): every lane is one reference worker stream
+    (the sampler that is bit-identical to the reference's per-thread sampling)."""
+    import torch
+    from gfasort_amd import hip
+    from gfasort_amd.distributed import HipEngine
+    eng = HipEngine(g, p, 0, int(p.min_term_updates), 0, args.streams, device_index=device_index,
+                    flags=args.flags | hip.F_BUNDLE(1), block_size=args.block)
+    eng.set_positions(hip.init_positions(g))
+    for k in range(3):
+        eng.run_iteration(k)
+    torch.cuda.synchronize()
+    s0 = eng.stats()
+    t0 = time.perf_counter()
+    for k in range(3, 3 + steps):
+        eng.run_iteration(k % (int(p.iter_max) + 1))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = eng.stats()
+    upd = s1.term_updates - s0.term_updates
+    kms = (s1.kernel_ms - s0.kernel_ms) / steps
+    eng.close()
+    return {"value": upd / dt, "unit": "term-updates/s", "steps": steps, "sampling_bundle": 1,
+            "avg_launch_ms": kms, "roofline_frac": (upd / steps) * ALGO_BYTES_1D / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +110,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--bundle", type=int, default=0, help="sampling bundle: 0 = library auto policy, 1 = reference streams")
     ap.add_argument("--block", type=int, default=0)
     args = ap.parse_args()
 
@@ -108,7 +135,8 @@ def main():
     g, p = build_workload()
     M = int(p.min_term_updates)
     runner = ShardedSGD(g, p, rank, world,
-                        hip_engine_factory(device_index=local_rank, flags=args.flags, block_size=args.block),
+                        hip_engine_factory(device_index=local_rank, flags=args.flags | hip.F_BUNDLE(args.bundle),
+                                           block_size=args.block),
                         dims=0, streams_per_rank=args.streams, dist=dist if world > 1 else None)
     x0 = hip.init_positions(g)
     n_sched = int(p.iter_max) + 1
@@ -171,14 +199,18 @@ def main():
             "config": {"workload": "windows(N=1000000,P=64,W=156250,seed=2): 1M nodes / 64 paths / 10M steps, "
                                    "-p Y --iter-max 200, 1e7 term updates per step",
                        "term_updates_per_step": M, "n_streams_per_gpu": int(st1.n_streams),
+                       "sampling_bundle": int(st1.bundle),
                        "parallelism": f"paths sharded x{world}, positions replicated, delta all-reduce/iter"
                        if world > 1 else "single GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gfs::sgd1d_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "kernel": "gfs::sgd1d_bundle_kernel" if int(st1.bundle) != 1 else "gfs::sgd1d_kernel",
+                         "avg_launch_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_update": ALGO_BYTES_1D},
             "total_term_updates": total_updates,
         }
+        if world == 1 and int(st1.bundle) != 1:
+            out["reference_streams"] = reference_streams_leg(g, p, local_rank, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, p)
         print(json.dumps(out), flush=True)

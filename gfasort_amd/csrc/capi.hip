@@ -273,8 +273,10 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     if (c->block % 64 || c->block > 1024) return fail(GFS_E_ARG, "block_size must be a multiple of 64, <= 1024");
     uint64_t T = c->cfg.n_streams;
     if (T == 0) {
-        // fill the chip (2048 resident lanes per CU) but keep >= 8 updates per stream per batch
-        uint64_t chip = (uint64_t)c->cu_count * 2048;
+        // 512 lanes per CU (2 waves per SIMD) measured best for every bundle width on MI355X
+        // (profiles/r01/sweep_streams.log): more resident waves only lengthen the queues in front
+        // of the memory-side atomic units.  Keep >= 8 updates per stream per batch on small graphs.
+        uint64_t chip = (uint64_t)c->cu_count * 512;
         uint64_t want = (c->quota_total + 7) / 8;
         T = std::max<uint64_t>(64, std::min<uint64_t>(chip, (want + 63) / 64 * 64));
     }

@@ -168,14 +168,19 @@ __global__ void sgd1d_bundle_kernel(const KArgs a) {
         wave_done += nvalid < remaining ? nvalid : remaining;
         if (!valid) continue;
         double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                           // :518-520
-        double dx = load_pos<ATOMIC_LOADS>(x + i) - load_pos<ATOMIC_LOADS>(x + j);     // :541-543
+        double dx;
+        if (a.dbg & 2u) dx = (double)i - (double)j;                                    // ablation: no position loads
+        else dx = load_pos<ATOMIC_LOADS>(x + i) - load_pos<ATOMIC_LOADS>(x + j);       // :541-543
         if (dx == 0.0) dx = 1e-9;                                                      // :546-548
         double mag = fabs(dx);                                                         // :551
         double delta = mu * (mag - term_dist) / 2.0;                                   // :552
         double r = delta / mag;                                                        // :570
         double r_x = r * dx;                                                           // :571
-        add_pos(x + i, -r_x);                                                          // :575
-        add_pos(x + j, r_x);                                                           // :576
+        if (a.dbg & 1u) { asm volatile("" :: "v"(r_x)); }                              // ablation: no atomics
+        else {
+            add_pos(x + i, -r_x);                                                      // :575
+            add_pos(x + j, r_x);                                                       // :576
+        }
         ++done;                                                                        // :579
         if (TRACE) {
             if (ntr < a.trace_per_stream) {
