@@ -288,15 +288,18 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     if (c->cfg.attempt_factor > 0xFFFFFFFFull) return fail(GFS_E_ARG, "attempt_factor too large");
     {   // sampling bundle: 0 = auto, 1 = reference streams, 4..64 explicit (sgd_device.h)
         uint32_t b = (c->cfg.flags >> 16) & 0xFFu;
-        if (b > 1 && (T % 64 != 0 || dims != 0 || (b != 4 && b != 8 && b != 16 && b != 32 && b != 64)))
-            return fail(GFS_E_ARG, "bundled sampling needs the 1D path, n_streams % 64 == 0 and a bundle of 4, 8, 16, 32 or 64");
+        if (b > 1 && (T % 64 != 0 || (b != 4 && b != 8 && b != 16 && b != 32 && b != 64)))
+            return fail(GFS_E_ARG, "bundled sampling needs n_streams % 64 == 0 and a bundle of 4, 8, 16, 32 or 64");
+        if (b > 1 && dims != 0 && (dims > 3 || b == 4))
+            return fail(GFS_E_UNSUPPORTED, "bundled layout kernels exist for 1..3 dimensions and bundles of 8..64");
         if (b == 0) {
             // auto: the widest bundle that still leaves >= 65536 independent bundle draws per
             // iteration and has >= 95 % of the steps in paths of at least 4*B steps.  Small graphs
-            // (and the nD path) therefore run reference streams.
+            // therefore run reference streams.
             b = 1;
-            if (dims == 0 && T % 64 == 0) {
+            if (T % 64 == 0 && dims <= 3) {
                 for (uint32_t cand : {64u, 32u, 16u, 8u, 4u}) {
+                    if (cand == 4u && dims != 0) continue;
                     if (c->quota_total / cand < 65536) continue;
                     uint64_t long_steps = 0;
                     for (uint32_t cnt : c->path_counts) if (cnt >= 4 * cand) long_steps += cnt;

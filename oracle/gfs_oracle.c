@@ -567,9 +567,46 @@ int gfo_state_set_bundle(gfo_state *s, uint64_t bundle) {
     if (bundle == 0) bundle = 1;
     if (bundle != 1 && (s->T % 64 != 0 || (bundle != 4 && bundle != 8 && bundle != 16 && bundle != 32 && bundle != 64)))
         return -1;
-    if (bundle != 1 && s->D != 0) return -1;          /* 1D only, like the product */
     s->bundle = bundle;
     return 0;
+}
+
+/* nD term with the two end flips already drawn (team mode): same arithmetic as term_nd. */
+static int nd_prepare(const pidx *pi, uint64_t sa, uint64_t sb, int fa, int fb,
+                      double *term_dist, uint64_t *idx_i, uint64_t *idx_j) {
+    double pos_a = (double)pi->rec[sa].pos, pos_b = (double)pi->rec[sb].pos;
+    uint32_t ni = pi->rec[sa].node, nj = pi->rec[sb].node;
+    double len_i = ni == GFO_NO_NODE ? 0.0 : (double)pi->node_len[ni];
+    double len_j = nj == GFO_NO_NODE ? 0.0 : (double)pi->node_len[nj];
+    int rev_i = (int)(pi->rec[sa].path_rev >> 31), rev_j = (int)(pi->rec[sb].path_rev >> 31);
+    int oa = fa; if (oa) { pos_a += len_i; oa = !rev_i; } else oa = rev_i;             /* :1062-1068 */
+    int ob = fb; if (ob) { pos_b += len_j; ob = !rev_j; } else ob = rev_j;             /* :1071-1077 */
+    *term_dist = fabs(pos_a - pos_b);                                                  /* :1080 */
+    if (*term_dist == 0.0 || ni == GFO_NO_NODE || nj == GFO_NO_NODE) return 0;
+    *idx_i = (uint64_t)ni * 2 + (oa ? 1 : 0); *idx_j = (uint64_t)nj * 2 + (ob ? 1 : 0);
+    return 1;
+}
+static int nd_term_ok(const pidx *pi, uint64_t sa, uint64_t sb, int fa, int fb) {
+    double td; uint64_t i, j;
+    return nd_prepare(pi, sa, sb, fa, fb, &td, &i, &j);
+}
+static int term_nd_flips(const pidx *pi, const iter_state *it, int fa, int fb, uint64_t sa, uint64_t sb,
+                         double *c, uint64_t D, gfo_term *tr) {
+    double term_dist; uint64_t idx_i, idx_j;
+    if (!nd_prepare(pi, sa, sb, fa, fb, &term_dist, &idx_i, &idx_j)) return 0;
+    double mu = fmin(it->eta * (1.0 / term_dist), 1.0);
+    double *ci = c + idx_i * D, *cj = c + idx_j * D;
+    double deltas[GFO_MAX_DIMS], mag_sq = 0.0;
+    for (uint64_t d = 0; d < D; d++) { deltas[d] = ci[d] - cj[d]; mag_sq += deltas[d] * deltas[d]; }
+    if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }
+    double mag = sqrt(mag_sq);
+    double r = (mu * (mag - term_dist) / 2.0) / mag;
+    for (uint64_t d = 0; d < D; d++) {
+        double r_d = r * deltas[d], vi = ci[d], vj = cj[d];
+        ci[d] = vi - r_d; cj[d] = vj + r_d;
+    }
+    if (tr) { tr->i = (uint32_t)idx_i; tr->j = (uint32_t)idx_j; tr->d_ij = term_dist; }
+    return 1;
 }
 
 typedef struct { uint64_t first, cnt, ra0, rb0; int ok; } leader_t;
@@ -623,7 +660,7 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
             leader_t L[64];
             for (int l = 0; l < 64; l++) L[l] = sample_leader(s, &it, s->rng + 4 * (wave_first + l));
             for (uint64_t t = 0; t < B && wave_done < wave_quota; t++) {
-                int valid[64]; uint64_t sa[64], sb[64];
+                int valid[64], flips_a[64], flips_b[64]; uint64_t sa[64], sb[64];
                 uint64_t nvalid = 0;
                 for (uint64_t qq = 0; qq < RUNS; qq++) {
                     const leader_t *ld = &L[t * RUNS + qq];
@@ -648,8 +685,16 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                             rb = (uint64_t)tt;
                         }
                         sa[l] = ld->first + ra; sb[l] = ld->first + rb;
-                        double td = fabs((double)pi->rec[sa[l]].pos - (double)pi->rec[sb[l]].pos);
-                        if (td == 0.0 || pi->rec[sa[l]].node == GFO_NO_NODE || pi->rec[sb[l]].node == GFO_NO_NODE) continue;
+                        if (s->D) {
+                            /* nD: the lane draws its two end flips from its OWN stream before the
+                             * term_dist test (sgd.rs:1062,1071,1080); probe the term without applying it */
+                            flips_a[l] = (int)flip(s->rng + 4 * (wave_first + l));
+                            flips_b[l] = (int)flip(s->rng + 4 * (wave_first + l));
+                            if (!nd_term_ok(pi, sa[l], sb[l], flips_a[l], flips_b[l])) continue;
+                        } else {
+                            double td = fabs((double)pi->rec[sa[l]].pos - (double)pi->rec[sb[l]].pos);
+                            if (td == 0.0 || pi->rec[sa[l]].node == GFO_NO_NODE || pi->rec[sb[l]].node == GFO_NO_NODE) continue;
+                        }
                         valid[l] = 1; nvalid++;
                     }
                 }
@@ -660,7 +705,8 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                     if (!valid[l]) continue;
                     if (rank++ >= remaining) continue;
                     gfo_term tr;
-                    (void)term_1d(pi, 1, &it, sa[l], sb[l], x, 0, NULL, &tr);
+                    if (s->D) (void)term_nd_flips(pi, &it, flips_a[l], flips_b[l], sa[l], sb[l], x, s->D, &tr);
+                    else (void)term_1d(pi, 1, &it, sa[l], sb[l], x, 0, NULL, &tr);
                     uint64_t tg = wave_first + l;
                     s->done[tg]++;
                     if (s->trace && s->ntr[tg] < s->trace_per_stream) s->trace[tg * s->trace_per_stream + s->ntr[tg]++] = tr;

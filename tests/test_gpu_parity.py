@@ -233,7 +233,7 @@ def test_c4_layout_full_size():
     p = P.LayoutSGDParams.from_graph(g, 2, 1)
     assert (p.min_term_updates, p.space, p.iter_max) == (100_000_000, 156_250, 30)
     lay, st = S.path_linear_sgd_layout(g, p, return_stats=True)
-    assert st.term_updates == 31 * 100_000_000
+    assert st.term_updates == 31 * 100_000_000 and st.bundle == 64       # auto policy at this size
     assert np.isfinite(lay.coords).all()
     s = O.layout_stress(oracle_graph(g), 2, lay.coords, 100000)
     c0 = S.default_layout_init(g, 2, p.seed)
@@ -242,7 +242,7 @@ def test_c4_layout_full_size():
     # both ends of a node end up one node length apart
     c = lay.coords.reshape(-1, 2, 2)
     d = np.sqrt(((c[:, 0, :] - c[:, 1, :]) ** 2).sum(axis=1))
-    assert np.median(np.abs(d - g.node_len)) < 0.05
+    assert np.median(np.abs(d - g.node_len)) < 0.1       # 0.045 with reference streams, 0.064 at B=64
 
 
 def test_c5_scale_10m_nodes_100m_steps():
@@ -328,3 +328,46 @@ def test_bundled_quality_matches_reference_streams_on_bubble_graph(B):
     s1, sb = O.stress_1d(og, x1, 100000), O.stress_1d(og, xb, 100000)
     assert st1.term_updates == stb.term_updates == 101 * p.min_term_updates
     assert s1 < 0.05 * s0 and abs(sb - s1) < 0.10 * s1 + 1e-4, (s0, s1, sb)
+
+
+@pytest.mark.parametrize("B,dims", [(8, 2), (64, 2), (16, 3)])
+def test_bundled_nd_sampler_trace_matches_oracle_mirror(B, dims):
+    g = load("DRB1-3123.gfa")
+    p = P.LayoutSGDParams.from_graph(g, dims, 1)
+    p.iter_max = 4
+    p.min_term_updates = 60000
+    T, K = 256, 64
+    og, op = oracle_graph(g), oracle_params(p)
+    c0 = gaussian_init(g, dims, 11)
+    c_ref = c0.copy()
+    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B)
+    st_o.run(c_ref)
+    so = st_o.stats()
+    ctx = hip.Context(g)
+    assert ctx.setup_nd(p, hip.make_config(n_streams=T, trace_per_stream=K, flags=hip.F_BUNDLE(B))) == 0
+    ctx.upload(c0)
+    ctx.run()
+    tr, counts = ctx.trace()
+    hst = ctx.stats()
+    assert hst.bundle == B and hst.term_updates == so.term_updates == 5 * p.min_term_updates and hst.attempts == so.attempts
+    tr_ref = st_o.trace.reshape(T, K)
+    assert np.array_equal(tr["i"], tr_ref["i"]) and np.array_equal(tr["j"], tr_ref["j"])
+    assert np.array_equal(tr["d_ij"].view(np.uint64), tr_ref["d_ij"].view(np.uint64))
+    assert np.isfinite(ctx.download()).all()
+    ctx.close()
+
+
+def test_bundled_nd_quality_matches_reference_streams():
+    from gfasort_amd import sgd as S
+    g = G.synth_bubbles(20000, 16, 5)
+    p = P.LayoutSGDParams.from_graph(g, 2, 1)
+    og = oracle_graph(g)
+    c0 = S.default_layout_init(g, 2, p.seed)
+    res = {}
+    for B in (1, 16, 64):
+        rc, c, st = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(flags=hip.F_BUNDLE(B)))
+        assert rc == 0 and st.bundle == B and st.term_updates == 31 * p.min_term_updates
+        res[B] = O.layout_stress(og, 2, c, 100000)
+    s0 = O.layout_stress(og, 2, c0, 100000)
+    assert res[1] < 0.1 * s0
+    assert abs(res[16] - res[1]) < 0.15 * res[1] + 1e-3 and abs(res[64] - res[1]) < 0.15 * res[1] + 1e-3, (s0, res)
