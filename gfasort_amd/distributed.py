@@ -53,6 +53,25 @@ def shard_quotas(total_updates: int, shard_steps: List[int]) -> List[int]:
     return base
 
 
+def path_order_layout(g: FlatGraph) -> np.ndarray:
+    """perm[k] = rank of dense node k in first-visit path order (unvisited nodes last): the same
+    rule libgfasort_hip applies by default, computed on the WHOLE graph so that every rank of a
+    multi-GPU run stores its position replica in the same order."""
+    n = g.n_nodes
+    valid = g.step_node[g.step_node != 0xFFFFFFFF].astype(np.int64)
+    perm = np.full(n, -1, dtype=np.int64)
+    if valid.size:
+        uniq, first = np.unique(valid, return_index=True)
+        visited = uniq[np.argsort(first, kind="stable")]
+        perm[visited] = np.arange(visited.size)
+        nxt = visited.size
+    else:
+        nxt = 0
+    rest = np.flatnonzero(perm < 0)
+    perm[rest] = nxt + np.arange(rest.size)
+    return perm.astype(np.uint32)
+
+
 def subgraph(g: FlatGraph, path_ids: List[int]) -> FlatGraph:
     """The graph restricted to some paths; all nodes are kept (positions are replicated)."""
     first = g.path_first_step.astype(np.int64)
@@ -87,6 +106,8 @@ class ShardedSGD:
         self.local_graph = local
         self.params = params
         self.stream_stride = streams_per_rank
+        # one node layout for all ranks (each rank only sees its own paths)
+        local.shared_node_layout = path_order_layout(graph) if world > 1 else None
         self.engine = engine_factory(local, params, dims, self.quotas[rank], rank, streams_per_rank)
         self.x_prev = None
         if world > 1:
@@ -123,6 +144,9 @@ class ShardedSGD:
             self.run_iteration(k)
 
     def positions_numpy(self) -> np.ndarray:
+        """Positions in the ABI's dense-index order."""
+        if hasattr(self.engine, "get_positions"):
+            return self.engine.get_positions()
         return self.engine.positions.detach().cpu().numpy().copy()
 
 
@@ -137,7 +161,9 @@ class HipEngine:
         self._torch = torch
         self.hip = hip
         self.device = torch.device("cuda", device_index)
-        self.ctx = hip.Context(local_graph, device=device_index)
+        self.ctx = hip.Context(local_graph, device=device_index,
+                               node_perm=getattr(local_graph, "shared_node_layout", None))
+        self.dims = dims
         cfg = hip.make_config(n_streams=streams_per_rank, stream_base=rank * (streams_per_rank or (1 << 20)),
                               term_updates_per_iteration=quota, flags=flags, block_size=block_size)
         self.cfg = cfg
@@ -149,9 +175,12 @@ class HipEngine:
             self.ctx.bind_positions(self.positions.data_ptr())
 
     def set_positions(self, x):
-        t = self._torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
-        self.positions.copy_(t)
+        # through the ABI: it applies the context's internal node layout
+        self.ctx.upload(np.ascontiguousarray(x, dtype=np.float64))
         self._torch.cuda.synchronize(self.device)
+
+    def get_positions(self):
+        return self.ctx.download()
 
     def reset_streams(self):
         self.ctx.reset_streams()

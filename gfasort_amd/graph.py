@@ -31,6 +31,7 @@ class FlatGraph:
     sequences: Optional[List[bytes]] = None          # by dense idx
     edges: Optional[List[Tuple[int, bool, int, bool]]] = None   # (from_id, from_rev, to_id, to_rev)
     step_node_id: Optional[np.ndarray] = None        # uint64[S] original ids of steps (for absent nodes)
+    shared_node_layout: Optional[np.ndarray] = None  # multi-GPU: internal node layout common to all ranks
 
     @property
     def n_nodes(self):

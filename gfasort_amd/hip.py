@@ -63,6 +63,7 @@ EXPORTS = [
     "gfs_version", "gfs_last_error", "gfs_device_count", "gfs_fast_precise_pow", "gfs_sgd_schedule",
     "gfs_zeta_table_len", "gfs_zeta_table", "gfs_init_positions", "gfs_init_layout_dim0",
     "gfs_sort_order", "gfs_path_linear_sgd", "gfs_path_linear_sgd_layout", "gfs_ctx_create",
+    "gfs_ctx_create_with_layout", "gfs_ctx_node_layout",
     "gfs_ctx_destroy", "gfs_ctx_setup_1d", "gfs_ctx_setup_nd", "gfs_ctx_positions_len",
     "gfs_ctx_upload_positions", "gfs_ctx_download_positions", "gfs_ctx_positions_device",
     "gfs_ctx_bind_positions", "gfs_ctx_reset_streams", "gfs_ctx_run_iteration", "gfs_ctx_run",
@@ -105,6 +106,7 @@ def lib():
         L.gfs_ctx_download_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gfs_ctx_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.gfs_ctx_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.gfs_ctx_node_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gfs_ctx_setup_1d.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.gfs_ctx_setup_nd.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.gfs_sort_order.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
@@ -200,11 +202,13 @@ def sort_order(x):
 class Context:
     """gfs_ctx: the graph's PathIndex mirror, positions and RNG streams resident in HBM."""
 
-    def __init__(self, g, device=0):
+    def __init__(self, g, device=0, node_perm=None):
         self._h = C.c_void_p()
         self.graph = g
         v, self._keep = make_view(g)
-        check(lib().gfs_ctx_create(C.byref(v), C.c_int(device), C.byref(self._h)))
+        if node_perm is not None:
+            node_perm = np.ascontiguousarray(node_perm, dtype=np.uint32)
+        check(lib().gfs_ctx_create_with_layout(C.byref(v), C.c_int(device), _ptr(node_perm), C.byref(self._h)))
         self.dims = 0
         self.params = None
         self.cfg = None
@@ -234,6 +238,12 @@ class Context:
 
     def positions_len(self):
         return int(lib().gfs_ctx_positions_len(self._h))
+
+    def node_layout(self):
+        """perm[k] = slot of dense node k in the device position vector."""
+        perm = np.zeros(self.graph.n_nodes, dtype=np.uint32)
+        check(lib().gfs_ctx_node_layout(self._h, _ptr(perm), C.c_uint64(perm.shape[0])))
+        return perm
 
     def upload(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -371,3 +371,36 @@ def test_bundled_nd_quality_matches_reference_streams():
     s0 = O.layout_stress(og, 2, c0, 100000)
     assert res[1] < 0.1 * s0
     assert abs(res[16] - res[1]) < 0.15 * res[1] + 1e-3 and abs(res[64] - res[1]) < 0.15 * res[1] + 1e-3, (s0, res)
+
+
+def test_internal_node_layout_is_path_order_and_invisible():
+    """The device stores positions in first-visit path order; upload/download/trace speak dense indices."""
+    from gfasort_amd.distributed import path_order_layout
+    g = load("DRB1-3123.gfa")
+    ctx = hip.Context(g)
+    perm = ctx.node_layout()
+    assert sorted(perm.tolist()) == list(range(g.n_nodes))
+    assert np.array_equal(perm, path_order_layout(g))
+    first_path_nodes = g.step_node[: int(g.path_first_step[1])]
+    _, idx = np.unique(first_path_nodes, return_index=True)
+    firsts = first_path_nodes[np.sort(idx)]
+    assert np.array_equal(perm[firsts], np.arange(firsts.shape[0]))       # path 0 occupies the first slots, in order
+    p = _ygs(g, 2)
+    ctx.setup_1d(p, hip.make_config(n_streams=1))
+    x0 = hip.init_positions(g)
+    ctx.upload(x0)
+    assert np.array_equal(ctx.download(), x0)                             # round trip through the layout
+    ctx.close()
+    # an explicit identity layout gives the same replay result as the default layout
+    ident = np.arange(g.n_nodes, dtype=np.uint32)
+    outs = []
+    for perm_in in (None, ident, np.random.default_rng(1).permutation(g.n_nodes).astype(np.uint32)):
+        c = hip.Context(g, node_perm=perm_in)
+        c.setup_1d(p, hip.make_config(n_streams=1))
+        c.upload(x0)
+        c.run()
+        outs.append(c.download())
+        c.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    with pytest.raises(hip.GfsError):
+        hip.Context(g, node_perm=np.zeros(g.n_nodes, dtype=np.uint32))
