@@ -102,6 +102,37 @@ def reference_streams_leg(g, p, device_index, args, steps=60):
             "avg_launch_ms": kms, "roofline_frac": (upd / steps) * ALGO_BYTES_1D / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def wall_clock_leg(g):
+    """The other half of BASELINE's metric: wall-clock of the whole `-p Y --iter-max 200` run,
+    GFA text in -> sorted GFA text out, through the C++ CLI (gfasort_amd/bin/gfasort_hip)."""
+    import subprocess
+    import tempfile
+    from gfasort_amd import build as B
+    if not os.path.exists(B.CLI):
+        return None
+    d = tempfile.mkdtemp(prefix="gfs_bench_")
+    src, dst = os.path.join(d, "c3.gfa"), os.path.join(d, "c3.sorted.gfa")
+    with open(src, "w") as fh:
+        fh.write("H\tVN:Z:1.0\n")
+        fh.write("".join(f"S\t{i}\t{'A' * l}\n" for i, l in zip(g.node_ids.tolist(), g.node_len.tolist())))
+        fh.write("".join(f"L\t{i}\t+\t{i + 1}\t+\t0M\n" for i in range(1, g.n_nodes)))
+        first = g.path_first_step.astype(np.int64)
+        for pth, name in enumerate(g.path_names):
+            fh.write(f"P\t{name}\t" + ",".join(f"{i}+" for i in g.step_node_id[first[pth]:first[pth + 1]].tolist()) + "\t*\n")
+    t0 = time.perf_counter()
+    r = subprocess.run([B.CLI, "-i", src, "-o", dst, "-p", "Y", "--iter-max", "200", "-v", "1"], capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    phases = [ln for ln in r.stderr.split("\n") if ln.startswith("[gfasort] done")]
+    out = {"seconds": dt, "returncode": r.returncode, "input_mb": os.path.getsize(src) / 1e6,
+           "command": "gfasort_hip -i c3.gfa -o c3.sorted.gfa -p Y --iter-max 200", "phases": phases[0] if phases else ""}
+    for f in (src, dst):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +243,7 @@ def main():
         if world == 1 and int(st1.bundle) != 1:
             out["reference_streams"] = reference_streams_leg(g, p, local_rank, args)
         if world == 1 and not args.no_cpu_baseline:
+            out["wall_clock_pY"] = wall_clock_leg(g)
             out["cpu_baseline"] = cpu_baseline(g, p)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -274,13 +274,16 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     if (c->block % 64 || c->block > 1024) return fail(GFS_E_ARG, "block_size must be a multiple of 64, <= 1024");
     uint64_t T = c->cfg.n_streams;
     if (T == 0) {
-        // 384 lanes per CU (1.5 waves per SIMD) measured best on MI355X for the team kernel and
-        // within 3 % of best for reference streams (profiles/r01/sweep_streams*.log): more resident
+        // 512 lanes per CU (2 waves per SIMD) measured best on MI355X for the team kernel and
+        // within 5 % of best for reference streams (profiles/r01/sweep_streams*.log): more resident
         // waves only lengthen the queues in front of the memory-side atomic units.  Keep >= 8
         // updates per stream per batch on small graphs.
-        uint64_t chip = (uint64_t)c->cu_count * 384;
+        uint64_t chip = (uint64_t)c->cu_count * 512;
         uint64_t want = (c->quota_total + 7) / 8;
-        T = std::max<uint64_t>(64, std::min<uint64_t>(chip, (want + 63) / 64 * 64));
+        // and never more than ~2 terms in flight per node: Hogwild staleness grows with
+        // streams / nodes (a 26k-node graph under 131072 streams lost 50 % layout quality)
+        uint64_t by_nodes = std::max<uint64_t>(64, (2 * c->n_nodes + 63) / 64 * 64);
+        T = std::max<uint64_t>(64, std::min<uint64_t>(std::min(chip, by_nodes), (want + 63) / 64 * 64));
     }
     if (T > 0x7FFFFFFFull) return fail(GFS_E_ARG, "n_streams too large");
     c->n_streams = T;

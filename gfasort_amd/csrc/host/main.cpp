@@ -77,6 +77,8 @@ int main(int argc, char **argv) {
     if (!parse_args(argc, argv, args)) { usage(); return 2; }
     if (validate_pipeline(args.pipeline)) return 1;
     auto t_start = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    double t_read = 0, t_parse = 0, t_steps = 0, t_write = 0;
     if (args.verbose >= 1) std::cerr << "[gfasort] reading " << args.input << "\n";
     std::string content;
     {
@@ -84,9 +86,12 @@ int main(int argc, char **argv) {
         if (!in) { std::cerr << "Error reading file: " << std::strerror(errno) << "\n"; return 1; }
         std::ostringstream ss; ss << in.rdbuf(); content = ss.str();
     }
+    t_read = since(t_start);
+    auto t_p0 = std::chrono::steady_clock::now();
     BidirectedGraph graph;
     try { graph = parse_gfa(content); }
     catch (const std::exception &e) { std::cerr << "Error parsing GFA: " << e.what() << "\n"; return 1; }
+    t_parse = since(t_p0);
     if (args.verbose >= 1)
         std::cerr << "[gfasort] loaded " << graph.node_count() << " nodes, " << graph.edges.size() << " edges, "
                   << graph.paths.size() << " paths\n";
@@ -102,6 +107,7 @@ int main(int argc, char **argv) {
 
     bool have_layout = false;
     Layout layout;
+    auto t_s0 = std::chrono::steady_clock::now();
     try {
         size_t step = 0;
         for (char c : args.pipeline) {
@@ -131,6 +137,8 @@ int main(int argc, char **argv) {
         std::cerr << "Error: " << e.what() << "\n";
         return 1;
     }
+    t_steps = since(t_s0);
+    auto t_w0 = std::chrono::steady_clock::now();
     if (have_layout) {
         if (!args.layout_out.empty()) {
             if (args.verbose >= 1) std::cerr << "[gfasort] writing layout to " << args.layout_out << "\n";
@@ -147,9 +155,11 @@ int main(int argc, char **argv) {
         if (!f) { std::cerr << "Error writing output file: " << std::strerror(errno) << "\n"; return 1; }
         graph.write_gfa(f);
     }
+    t_write = since(t_w0);
     if (args.verbose >= 1) {
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-        std::cerr << "[gfasort] done (" << s << " s wall)\n";
+        std::cerr << "[gfasort] done (" << s << " s wall: read " << t_read << ", parse " << t_parse << ", pipeline "
+                  << t_steps << ", write " << t_write << ")\n";
     }
     return 0;
 }
