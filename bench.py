@@ -157,11 +157,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU fallback")
+    # GFS_BENCH_SHARE_DEVICE=1 (rehearsal on a 1-GPU box): all ranks use cuda:0 and gloo, because
+    # RCCL refuses two ranks on one device.  The driver's real runs never set it.
+    share = os.environ.get("GFS_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     g, p = build_workload()
     M = int(p.min_term_updates)

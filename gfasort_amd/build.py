@@ -8,13 +8,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgfasort_hip.so")
-SOURCES = ["sgd_kernels.hip", "capi.hip"]
-HEADERS = ["sgd_device.h", os.path.join("..", "..", "include", "gfasort_hip.h")]
+SOURCES = ["sgd_kernels_1d.hip", "sgd_kernels_nd.hip", "sgd_kernels_nd_team.hip", "capi.hip"]
+HEADERS = ["sgd_device.h", "sgd_kernel_common.h", os.path.join("..", "..", "include", "gfasort_hip.h")]
 
 # -ffp-contract=off : the reference (Rust) never fuses a*b+c; device and host tables must match it
 # -munsafe-fp-atomics: native global_atomic_add_f64 on hipMalloc'ed (coarse-grained) memory
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+OBJDIR = os.path.join(HERE, "lib", "obj")
 
 
 def _stale():
@@ -28,9 +29,25 @@ def _stale():
 def build_hip(force=False, verbose=False):
     if not force and not _stale():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        sp = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_t):
+            return obj
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", "-o", obj, sp]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:     # one TU per kernel family
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

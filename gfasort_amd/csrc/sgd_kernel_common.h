@@ -1,0 +1,71 @@
+// sgd_kernel_common.h — shared pieces of the SGD batch kernels (gfx950 / CDNA4, wave64).
+//
+// K1  sgd1d_kernel : one launch = one SGD iteration of path_linear_sgd      (src/sgd.rs:442-584)
+// K2  sgdnd_kernel : one launch = one iteration of path_linear_sgd_layout   (src/sgd.rs:988-1156)
+//
+// Execution model: one lane = one Xoshiro256+ stream = one reference worker thread
+// (seed + stream id, sgd.rs:431-432).  A launch replaces the reference's checker thread
+// (sgd.rs:366-407): eta / theta / cooling are launch constants and every stream performs
+// exactly its quota of successful term updates, so the number of updates per iteration is
+// min_term_updates, not wall-clock dependent.
+//
+// Memory: this is an HBM/fabric-bound gather/scatter, no MFMA.  Per update the kernel touches
+// two 16-B step records (random), two (1D) position words read with agent-scope relaxed
+// atomic loads, and two no-return f64 atomic adds (global_atomic_add_f64: gfx950 has the
+// native instruction, so no CAS loop).  The zeta table and the per-path records are staged
+// once per workgroup into LDS.  RNG state lives in registers for the whole launch and is
+// loaded/stored coalesced (SoA) at entry/exit.
+#pragma once
+#include "sgd_device.h"
+
+namespace gfs {
+
+struct TraceTerm { uint32_t i, j; double d; };
+
+template <bool ATOMIC_LOADS>
+__device__ __forceinline__ double load_pos(const double *p) {
+    if (ATOMIC_LOADS)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+__device__ __forceinline__ void add_pos(double *p, double v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Stage zeta/path tables into LDS (or return the global pointers).
+template <bool LDS_TABLES>
+__device__ __forceinline__ void stage_tables(const KArgs &a, unsigned char *smem,
+                                             const uint4 *&path_tab, const double *&zeta_tab) {
+    if (LDS_TABLES) {
+        uint4 *lp = reinterpret_cast<uint4 *>(smem);
+        double *lz = reinterpret_cast<double *>(smem + (size_t)a.n_paths * sizeof(uint4));
+        for (uint32_t k = threadIdx.x; k < a.n_paths; k += blockDim.x) lp[k] = a.path_rec[k];
+        for (uint32_t k = threadIdx.x; k < a.zlen_staged; k += blockDim.x) lz[k] = a.zetas[k];
+        __syncthreads();
+        path_tab = lp; zeta_tab = lz;
+    } else {
+        path_tab = a.path_rec; zeta_tab = a.zetas;
+    }
+}
+
+__device__ __forceinline__ void flush_counters(const KArgs &a, uint32_t done, uint32_t att) {
+    // wave64 butterfly, one atomic per wave
+    unsigned long long d = done, t = att;
+    for (int off = 32; off > 0; off >>= 1) {
+        d += __shfl_xor(d, off, 64);
+        t += __shfl_xor(t, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&a.counters[0], d);
+        atomicAdd(&a.counters[1], t);
+    }
+}
+
+template <int B>
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int leader_lane) {
+    if (B == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, leader_lane);     // wave-uniform leader
+    return (uint32_t)__shfl((int)v, leader_lane, 64);
+}
+
+
+}  // namespace gfs

@@ -1,0 +1,261 @@
+// sgd_kernels_1d.hip — K1 (reference streams) and K1b (team kernel) of path_linear_sgd, plus the
+// multi-GPU replica-merge kernels.  See sgd_kernel_common.h / sgd_device.h.
+#include "sgd_kernel_common.h"
+
+namespace gfs {
+
+// ------------------------------------------------------------------------------------------
+// K1: 1D
+// ------------------------------------------------------------------------------------------
+template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__global__ void sgd1d_kernel(const KArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
+
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = tid < a.n_streams;
+    uint32_t done = 0, att = 0;
+    if (live) {
+        Rng rng;
+        const uint64_t T = a.n_streams;
+        rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid];
+        const uint32_t quota = a.quota_base + (tid < a.quota_rem ? 1u : 0u);
+        const uint64_t max_att64 = (uint64_t)a.attempt_factor * quota + 1024u;
+        const uint32_t max_att = max_att64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_att64;
+        uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
+        double *x = a.x;
+        while (done < quota && att < max_att) {
+            ++att;
+            uint4 ra, rb; uint32_t sa, sb, cnt, path;
+            if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) continue;
+            double term_dist = fabs(rec_pos(ra) - rec_pos(rb));                        // sgd.rs:513
+            if (term_dist == 0.0) continue;                                            // :514
+            double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                       // :518-520
+            const uint32_t i = ra.x, j = rb.x;
+            if (i == 0xFFFFFFFFu || j == 0xFFFFFFFFu) continue;                        // :525-538
+            double dx;
+            if (a.dbg & 2u) dx = (double)i - (double)j;                                // ablation: no position loads
+            else dx = load_pos<ATOMIC_LOADS>(x + i) - load_pos<ATOMIC_LOADS>(x + j);   // :541-543
+            if (dx == 0.0) dx = 1e-9;                                                  // :546-548
+            double mag = fabs(dx);                                                     // :551
+            double delta = mu * (mag - term_dist) / 2.0;                               // :552
+            double r = delta / mag;                                                    // :570
+            double r_x = r * dx;                                                       // :571
+            if (a.dbg & 1u) { asm volatile("" :: "v"(r_x)); }                          // ablation: no atomics
+            else {
+                add_pos(x + i, -r_x);                                                  // :575
+                add_pos(x + j, r_x);                                                   // :576
+            }
+            ++done;                                                                    // :579
+            if (TRACE) {
+                if (ntr < a.trace_per_stream) {
+                    TraceTerm *t = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                    t->i = i; t->j = j; t->d = term_dist;
+                    ++ntr;
+                }
+            }
+        }
+        a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;
+        if (TRACE) a.trace_cnt[tid] = ntr;
+    }
+    flush_counters(a, done, att);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1b: 1D team kernel — bundled ("run") sampling (sgd_device.h).  A wave is a team:
+//   pass   : all 64 lanes sample one leader term each from their own reference streams — the
+//            Zipf/f64 arithmetic runs at full SIMD width instead of on one lane per bundle;
+//   trips  : B trips execute the 64 leaders as 64/B runs of B lanes.  The records of trip t+1
+//            are requested before trip t is consumed, and (DEFER) the atomics of trip t are
+//            issued behind the position loads of trip t+1, so a trip exposes one memory round
+//            trip (its position loads) instead of three and never waits for its own atomics
+//            (vmcnt retires in order: an atomic issued before a load would be waited for).
+//            Deferring doubles the window in which a wave reads positions it is about to
+//            change; the host enables it only when in-flight terms are few relative to the
+//            number of nodes (4*n_streams <= n_nodes) — on small graphs with many streams the
+//            extra staleness pushed the concurrent corrections per node past stability.
+// The quota is per WAVE with a rank cut-off in the last trip: an iteration performs exactly its
+// number of updates; leaders left over when the quota fills are discarded.
+// ------------------------------------------------------------------------------------------
+template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__global__ void sgd1d_team_kernel(const KArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
+
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;       // n_streams % 64 == 0 (host-checked)
+    if (tid >= a.n_streams) return;                                   // whole waves only
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (B - 1);
+    const int q = lane / B;
+    constexpr int RUNS = 64 / B;                                      // runs per trip
+    const uint64_t T = a.n_streams;
+    Rng rng;
+    rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid];
+    // wave quota = sum of its 64 lanes' per-stream quotas
+    const uint32_t wave_first = tid & ~63u;
+    uint64_t wave_quota = (uint64_t)a.quota_base * 64u;
+    if (wave_first < a.quota_rem) wave_quota += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
+    const uint64_t max_passes = (uint64_t)a.attempt_factor * (wave_quota / (64u * B) + 1u) + 16u;
+    uint64_t wave_done = 0, passes = 0;
+    uint32_t done = 0, att = 0;
+    uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
+    double *x = a.x;
+    // deferred atomics of the previous trip
+    bool pend = false; uint32_t pend_i = 0, pend_j = 0; double pend_r = 0.0;
+
+    while (wave_done < wave_quota && passes < max_passes) {
+        ++passes;
+        const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
+        // trip 0: expand and request records
+        uint32_t sa = 0, sb = 0;
+        bool valid = expand_run<B>(bcast<B>(L.ok, q), bcast<B>(L.first, q), bcast<B>(L.cnt, q),
+                                   bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, sa, sb);
+        uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+        if (valid) { ra = a.step_rec[sa]; rb = a.step_rec[sb]; }
+#pragma unroll 2
+        for (int t = 0; t < B; ++t) {
+            // request the records of trip t+1
+            uint32_t sa_n = 0, sb_n = 0; bool valid_n = false;
+            uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = make_uint4(0, 0, 0, 0);
+            if (t + 1 < B) {
+                const int ll = (t + 1) * RUNS + q;
+                valid_n = expand_run<B>(bcast<B>(L.ok, ll), bcast<B>(L.first, ll), bcast<B>(L.cnt, ll),
+                                        bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa_n, sb_n);
+                if (valid_n) { ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n]; }
+            }
+            // consume trip t
+            ++att;
+            double term_dist = 0.0;
+            uint32_t i = 0, j = 0;
+            if (valid) {
+                term_dist = fabs(rec_pos(ra) - rec_pos(rb));                           // sgd.rs:513
+                i = ra.x; j = rb.x;
+                valid = term_dist != 0.0 && i != 0xFFFFFFFFu && j != 0xFFFFFFFFu;      // :514, :525-538
+            }
+            const unsigned long long vmask = __ballot(valid);
+            const uint64_t remaining = wave_quota - wave_done;
+            const uint32_t nvalid = (uint32_t)__popcll(vmask);
+            if (valid && nvalid > remaining) {
+                const uint32_t rank = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull));
+                valid = rank < remaining;
+            }
+            wave_done += nvalid < remaining ? nvalid : remaining;
+            double xi = 0.0, xj = 0.0;
+            if (valid) { xi = load_pos<ATOMIC_LOADS>(x + i); xj = load_pos<ATOMIC_LOADS>(x + j); }   // :541-542
+            if (DEFER) {
+                if (pend) { add_pos(x + pend_i, -pend_r); add_pos(x + pend_j, pend_r); }   // trip t-1's :575-576
+                pend = valid;
+            }
+            if (valid) {
+                double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                   // :518-520
+                double dx = xi - xj;                                                   // :543
+                if (dx == 0.0) dx = 1e-9;                                              // :546-548
+                double mag = fabs(dx);                                                 // :551
+                double delta = mu * (mag - term_dist) / 2.0;                           // :552
+                double r = delta / mag;                                                // :570
+                pend_r = r * dx; pend_i = i; pend_j = j;                               // :571
+                if (!DEFER) { add_pos(x + i, -pend_r); add_pos(x + j, pend_r); }       // :575-576
+                ++done;                                                                // :579
+                if (TRACE) {
+                    if (ntr < a.trace_per_stream) {
+                        TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                        tt->i = i; tt->j = j; tt->d = term_dist;
+                        ++ntr;
+                    }
+                }
+            }
+            if (wave_done >= wave_quota) break;                                        // leaders left over are discarded
+            ra = ra_n; rb = rb_n; sa = sa_n; sb = sb_n; valid = valid_n;
+        }
+    }
+    if (pend) { add_pos(x + pend_i, -pend_r); add_pos(x + pend_j, pend_r); }
+    a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;
+    if (TRACE) a.trace_cnt[tid] = ntr;
+    flush_counters(a, done, att);
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-GPU replica merge (no reference equivalent; gfasort_amd/distributed.py).  Two streaming
+// kernels around the one all-reduce of an iteration:
+//   prepare: buf[0][k] = x[k] - x_prev[k]  (this rank's batch),  buf[1][k] = delta != 0
+//   apply  : x_prev[k] += sum_delta[k] / max(1, sum_touched[k]);  x[k] = x_prev[k]
+// 16 B per lane, grid-stride; pure HBM streaming.
+// ------------------------------------------------------------------------------------------
+__global__ void merge_prepare_kernel(const double *x, const double *x_prev, double *buf, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 2;
+    for (uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; k < n; k += stride) {
+        if (k + 1 < n) {
+            const double2 a = *reinterpret_cast<const double2 *>(x + k), b = *reinterpret_cast<const double2 *>(x_prev + k);
+            double2 d = make_double2(a.x - b.x, a.y - b.y);
+            *reinterpret_cast<double2 *>(buf + k) = d;
+            *reinterpret_cast<double2 *>(buf + n + k) = make_double2(d.x != 0.0 ? 1.0 : 0.0, d.y != 0.0 ? 1.0 : 0.0);
+        } else {
+            double d = x[k] - x_prev[k];
+            buf[k] = d; buf[n + k] = d != 0.0 ? 1.0 : 0.0;
+        }
+    }
+}
+__global__ void merge_apply_kernel(double *x, double *x_prev, const double *buf, uint64_t n, double scale_all) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const double c = buf[n + k];
+        const double div = scale_all > 0.0 ? scale_all : (c > 1.0 ? c : 1.0);
+        const double v = x_prev[k] + buf[k] / div;
+        x_prev[k] = v; x[k] = v;
+    }
+}
+hipError_t launch_merge_prepare(const double *x, const double *x_prev, double *buf, uint64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(merge_prepare_kernel, dim3(2048), dim3(256), 0, st, x, x_prev, buf, n);
+    return hipGetLastError();
+}
+hipError_t launch_merge_apply(double *x, double *x_prev, const double *buf, uint64_t n, double scale_all, hipStream_t st) {
+    hipLaunchKernelGGL(merge_apply_kernel, dim3(2048), dim3(256), 0, st, x, x_prev, buf, n, scale_all);
+    return hipGetLastError();
+}
+
+template <bool L, bool A>
+static hipError_t launch_1d_t(const KArgs &a, bool trace, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (trace) hipLaunchKernelGGL((sgd1d_kernel<L, A, true>), grid, block, lds, st, a);
+    else       hipLaunchKernelGGL((sgd1d_kernel<L, A, false>), grid, block, lds, st, a);
+    return hipGetLastError();
+}
+template <int B, bool L, bool A>
+static hipError_t launch_1db_t(const KArgs &a, bool trace, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    const bool defer = (a.dbg & 0x80u) != 0;          // host decision, see capi.hip
+    if (trace) {                                      // debug trace: one variant (agent-scope loads, no deferral)
+        hipLaunchKernelGGL((sgd1d_team_kernel<B, false, L, true, true>), grid, block, lds, st, a);
+    } else if (defer) {
+        hipLaunchKernelGGL((sgd1d_team_kernel<B, true, L, A, false>), grid, block, lds, st, a);
+    } else {
+        hipLaunchKernelGGL((sgd1d_team_kernel<B, false, L, A, false>), grid, block, lds, st, a);
+    }
+    return hipGetLastError();
+}
+template <int B>
+static hipError_t launch_1db(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                             dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (lds_tables) return atomic_loads ? launch_1db_t<B, true, true>(a, trace, grid, block, lds, st)
+                                        : launch_1db_t<B, true, false>(a, trace, grid, block, lds, st);
+    return atomic_loads ? launch_1db_t<B, false, true>(a, trace, grid, block, 0, st)
+                        : launch_1db_t<B, false, false>(a, trace, grid, block, 0, st);
+}
+hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                     dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    switch (a.bundle) {
+        case 0: case 1:
+            if (lds_tables) return atomic_loads ? launch_1d_t<true, true>(a, trace, grid, block, lds, st)
+                                                : launch_1d_t<true, false>(a, trace, grid, block, lds, st);
+            return atomic_loads ? launch_1d_t<false, true>(a, trace, grid, block, 0, st)
+                                : launch_1d_t<false, false>(a, trace, grid, block, 0, st);
+        case 4:  return launch_1db<4>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 8:  return launch_1db<8>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 16: return launch_1db<16>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 32: return launch_1db<32>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        case 64: return launch_1db<64>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace gfs

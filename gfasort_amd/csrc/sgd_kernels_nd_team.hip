@@ -1,0 +1,159 @@
+// sgd_kernels_nd_team.hip — K2b: team (bundled) kernels of path_linear_sgd_layout, D = 1..3, and the
+// nD launch dispatcher.
+#include "sgd_kernel_common.h"
+
+namespace gfs {
+
+hipError_t launch_nd_ref(int dims, const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                         dim3 grid, dim3 block, size_t lds, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// K2b: nD team kernel — the pass/trip structure of K1b for path_linear_sgd_layout.  Each acting
+// lane draws its two end flips (sgd.rs:1062,1071) from its OWN stream; node lengths come from the
+// following step record as in K2.  A run of B consecutive nodes is 32*B contiguous coordinate
+// bytes for D = 2 (Layout order), so coordinate loads and atomics coalesce like the 1D positions.
+// Atomics are issued in the trip that computes them (no deferral).
+// ------------------------------------------------------------------------------------------
+template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__global__ void sgdnd_team_kernel(const KArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
+
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= a.n_streams) return;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (B - 1);
+    const int q = lane / B;
+    constexpr int RUNS = 64 / B;
+    const uint64_t T = a.n_streams;
+    Rng rng;
+    rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid];
+    const uint32_t wave_first = tid & ~63u;
+    uint64_t wave_quota = (uint64_t)a.quota_base * 64u;
+    if (wave_first < a.quota_rem) wave_quota += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
+    const uint64_t max_passes = (uint64_t)a.attempt_factor * (wave_quota / (64u * B) + 1u) + 16u;
+    uint64_t wave_done = 0, passes = 0;
+    uint32_t done = 0, att = 0;
+    uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
+
+    while (wave_done < wave_quota && passes < max_passes) {
+        ++passes;
+        const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
+        uint32_t sa = 0, sb = 0;
+        uint32_t first = bcast<B>(L.first, q), cnt = bcast<B>(L.cnt, q);
+        bool valid = expand_run<B>(bcast<B>(L.ok, q), first, cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, sa, sb);
+        uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, na = ra, nb = ra;
+        if (valid) {
+            ra = a.step_rec[sa]; rb = a.step_rec[sb];
+            na = a.step_rec[sa + 1u < a.n_steps ? sa + 1u : sa]; nb = a.step_rec[sb + 1u < a.n_steps ? sb + 1u : sb];
+        }
+#pragma unroll 2
+        for (int t = 0; t < B; ++t) {
+            uint32_t sa_n = 0, sb_n = 0, first_n = 0, cnt_n = 0; bool valid_n = false;
+            uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = ra_n, na_n = ra_n, nb_n = ra_n;
+            if (t + 1 < B) {
+                const int ll = (t + 1) * RUNS + q;
+                first_n = bcast<B>(L.first, ll); cnt_n = bcast<B>(L.cnt, ll);
+                valid_n = expand_run<B>(bcast<B>(L.ok, ll), first_n, cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa_n, sb_n);
+                if (valid_n) {
+                    ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n];
+                    na_n = a.step_rec[sa_n + 1u < a.n_steps ? sa_n + 1u : sa_n];
+                    nb_n = a.step_rec[sb_n + 1u < a.n_steps ? sb_n + 1u : sb_n];
+                }
+            }
+            ++att;
+            double term_dist = 0.0;
+            uint64_t idx_i = 0, idx_j = 0;
+            if (valid) {
+                const uint32_t last_step = first + cnt - 1u;
+                const uint64_t plen = a.path_len[ra.y & 0x7FFFFFFFu];
+                const uint64_t pa = ((uint64_t)ra.w << 32) | ra.z, pb = ((uint64_t)rb.w << 32) | rb.z;
+                const uint64_t ea = sa == last_step ? plen : (((uint64_t)na.w << 32) | na.z);
+                const uint64_t eb = sb == last_step ? plen : (((uint64_t)nb.w << 32) | nb.z);
+                double pos_a = (double)pa, pos_b = (double)pb;                         // sgd.rs:1047-1048
+                const double len_i = (double)(ea - pa), len_j = (double)(eb - pb);     // :1051-1058
+                const bool rev_i = (ra.y >> 31) != 0, rev_j = (rb.y >> 31) != 0;
+                bool oa = rng.flip() == 1u;                                            // :1062
+                if (oa) { pos_a += len_i; oa = !rev_i; } else { oa = rev_i; }
+                bool ob = rng.flip() == 1u;                                            // :1071
+                if (ob) { pos_b += len_j; ob = !rev_j; } else { ob = rev_j; }
+                term_dist = fabs(pos_a - pos_b);                                       // :1080
+                valid = term_dist != 0.0 && ra.x != 0xFFFFFFFFu && rb.x != 0xFFFFFFFFu;   // :1081, :1089-1096
+                idx_i = (uint64_t)ra.x * 2u + (oa ? 1u : 0u);                          // :1099-1103
+                idx_j = (uint64_t)rb.x * 2u + (ob ? 1u : 0u);
+            }
+            const unsigned long long vmask = __ballot(valid);
+            const uint64_t remaining = wave_quota - wave_done;
+            const uint32_t nvalid = (uint32_t)__popcll(vmask);
+            if (valid && nvalid > remaining) {
+                const uint32_t rank = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull));
+                valid = rank < remaining;
+            }
+            wave_done += nvalid < remaining ? nvalid : remaining;
+            if (valid) {
+                double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                   // :1085-1086
+                double *ci = a.x + idx_i * D, *cj = a.x + idx_j * D;
+                double deltas[D];
+                double mag_sq = 0.0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {                                          // :1108-1113
+                    deltas[d] = load_pos<ATOMIC_LOADS>(ci + d) - load_pos<ATOMIC_LOADS>(cj + d);
+                    mag_sq += deltas[d] * deltas[d];
+                }
+                if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }               // :1116-1119
+                double mag = sqrt(mag_sq);                                             // :1121
+                double delta = mu * (mag - term_dist) / 2.0;                           // :1125
+                double r = delta / mag;                                                // :1142
+                const bool same = idx_i == idx_j;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {                                          // :1143-1149
+                    double r_d = r * deltas[d];
+                    if (!same) add_pos(ci + d, -r_d);
+                    add_pos(cj + d, r_d);
+                }
+                ++done;                                                                // :1151
+                if (TRACE) {
+                    if (ntr < a.trace_per_stream) {
+                        TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                        tt->i = (uint32_t)idx_i; tt->j = (uint32_t)idx_j; tt->d = term_dist;
+                        ++ntr;
+                    }
+                }
+            }
+            if (wave_done >= wave_quota) break;
+            ra = ra_n; rb = rb_n; na = na_n; nb = nb_n; sa = sa_n; sb = sb_n; valid = valid_n; first = first_n; cnt = cnt_n;
+        }
+    }
+    a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;
+    if (TRACE) a.trace_cnt[tid] = ntr;
+    flush_counters(a, done, att);
+}
+
+template <int D, int B>
+static hipError_t launch_ndb(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                             dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    // team kernel variants: LDS tables on/off; agent-scope loads; trace on/off
+    (void)atomic_loads;                               // team layout kernels always use agent-scope loads
+    if (lds_tables) {
+        if (trace) hipLaunchKernelGGL((sgdnd_team_kernel<D, B, true, true, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((sgdnd_team_kernel<D, B, true, true, false>), grid, block, lds, st, a);
+    } else {
+        if (trace) hipLaunchKernelGGL((sgdnd_team_kernel<D, B, false, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((sgdnd_team_kernel<D, B, false, true, false>), grid, block, 0, st, a);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
+                     dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (dims >= 1 && dims <= 3 && a.bundle >= 8) {
+#define GFS_NDB_CASE(D, B) if (dims == D && a.bundle == B) return launch_ndb<D, B>(a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+        GFS_NDB_CASE(1, 8) GFS_NDB_CASE(1, 16) GFS_NDB_CASE(1, 32) GFS_NDB_CASE(1, 64)
+        GFS_NDB_CASE(2, 8) GFS_NDB_CASE(2, 16) GFS_NDB_CASE(2, 32) GFS_NDB_CASE(2, 64)
+        GFS_NDB_CASE(3, 8) GFS_NDB_CASE(3, 16) GFS_NDB_CASE(3, 32) GFS_NDB_CASE(3, 64)
+#undef GFS_NDB_CASE
+    }
+    return launch_nd_ref(dims, a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+}
+
+}  // namespace gfs

@@ -110,6 +110,7 @@ class ShardedSGD:
         local.shared_node_layout = path_order_layout(graph) if world > 1 else None
         self.engine = engine_factory(local, params, dims, self.quotas[rank], rank, streams_per_rank)
         self.x_prev = None
+        self._buf = None
         if world > 1:
             import torch
             self._torch = torch
@@ -125,19 +126,24 @@ class ShardedSGD:
         if self.world > 1:
             torch = self._torch
             x = self.engine.positions
-            if self.merge == "touch":
-                buf = torch.empty((2, x.shape[0]), dtype=x.dtype, device=x.device)
+            n = x.shape[0]
+            if self._buf is None:
+                self._buf = torch.empty((2, n), dtype=x.dtype, device=x.device)
+            buf = self._buf
+            divide = {"touch": 0.0, "sum": 1.0, "mean": float(self.world)}[self.merge]
+            if x.is_cuda and hasattr(self.engine, "hip"):
+                # fused HIP kernels on the engine's stream around the one collective
+                st = torch.cuda.current_stream(x.device).cuda_stream
+                self.engine.hip.merge_prepare(x.data_ptr(), self.x_prev.data_ptr(), buf.data_ptr(), n, st)
+                self.dist.all_reduce(buf)                 # RCCL over xGMI
+                self.engine.hip.merge_apply(x.data_ptr(), self.x_prev.data_ptr(), buf.data_ptr(), n, divide, st)
+            else:
                 torch.sub(x, self.x_prev, out=buf[0])     # this rank's batch
                 buf[1] = (buf[0] != 0).to(x.dtype)
-                self.dist.all_reduce(buf)                 # one collective (RCCL over xGMI on GPUs)
-                self.x_prev += buf[0] / buf[1].clamp_(min=1.0)
-            else:
-                delta = x - self.x_prev
-                self.dist.all_reduce(delta)
-                if self.merge == "mean":
-                    delta /= self.world
-                self.x_prev += delta
-            x.copy_(self.x_prev)
+                self.dist.all_reduce(buf)
+                div = buf[1].clamp_(min=1.0) if divide == 0.0 else divide
+                self.x_prev += buf[0] / div
+                x.copy_(self.x_prev)
 
     def run(self):
         for k in range(int(self.params.iter_max) + 1):

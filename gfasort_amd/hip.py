@@ -67,7 +67,7 @@ EXPORTS = [
     "gfs_ctx_destroy", "gfs_ctx_setup_1d", "gfs_ctx_setup_nd", "gfs_ctx_positions_len",
     "gfs_ctx_upload_positions", "gfs_ctx_download_positions", "gfs_ctx_positions_device",
     "gfs_ctx_bind_positions", "gfs_ctx_reset_streams", "gfs_ctx_run_iteration", "gfs_ctx_run",
-    "gfs_ctx_synchronize", "gfs_ctx_stats", "gfs_ctx_trace",
+    "gfs_ctx_synchronize", "gfs_ctx_stats", "gfs_ctx_trace", "gfs_merge_prepare", "gfs_merge_apply",
 ]
 
 _lib = None
@@ -110,6 +110,8 @@ def lib():
         L.gfs_ctx_setup_1d.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.gfs_ctx_setup_nd.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.gfs_sort_order.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.gfs_merge_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.gfs_merge_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         _lib = L
     return _lib
 
@@ -196,6 +198,16 @@ def sort_order(x):
     order = np.zeros(x.shape[0], dtype=np.uint64)
     check(lib().gfs_sort_order(_ptr(x), x.shape[0], _ptr(order)))
     return order
+
+
+def merge_prepare(x_ptr, x_prev_ptr, buf_ptr, n, stream=None):
+    check(lib().gfs_merge_prepare(C.c_void_p(x_ptr), C.c_void_p(x_prev_ptr), C.c_void_p(buf_ptr), C.c_uint64(n),
+                                  C.c_void_p(stream or 0)))
+
+
+def merge_apply(x_ptr, x_prev_ptr, buf_ptr, n, divide_all_by=0.0, stream=None):
+    check(lib().gfs_merge_apply(C.c_void_p(x_ptr), C.c_void_p(x_prev_ptr), C.c_void_p(buf_ptr), C.c_uint64(n),
+                                C.c_double(divide_all_by), C.c_void_p(stream or 0)))
 
 
 # ---- resident context ------------------------------------------------------------------------

@@ -404,3 +404,54 @@ def test_internal_node_layout_is_path_order_and_invisible():
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     with pytest.raises(hip.GfsError):
         hip.Context(g, node_perm=np.zeros(g.n_nodes, dtype=np.uint32))
+
+
+# ---- the N>1 path on real hardware: two ranks share the one GPU over gloo --------------------------------
+def _mp_rank(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gfasort_amd.distributed import ShardedSGD, hip_engine_factory
+    g = G.synth_bubbles(20000, 16, 5)
+    p = _ygs(g, 100)
+    r = ShardedSGD(g, p, rank, world, hip_engine_factory(device_index=0), dims=0, dist=dist)
+    r.set_positions(hip.init_positions(g))
+    r.run()
+    torch.cuda.synchronize()
+    x = r.positions_numpy()
+    st = r.engine.stats()
+    xs = [torch.zeros(x.shape[0], dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(xs, torch.from_numpy(x))
+    upd = torch.tensor([float(st.term_updates)], dtype=torch.float64)
+    dist.all_reduce(upd)
+    if rank == 0:
+        out.put((x, [t.numpy() for t in xs], float(upd.item()), r.quotas, int(st.bundle), int(st.n_streams)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_hip_engine():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_mp_rank, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    x, xs, upd, quotas, bundle, streams = out.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    g = G.synth_bubbles(20000, 16, 5)
+    p = _ygs(g, 100)
+    assert np.array_equal(xs[0], xs[1])                                   # replicas agree after the merge
+    assert sum(quotas) == p.min_term_updates and upd == 101 * p.min_term_updates
+    og = oracle_graph(g)
+    s0 = O.stress_1d(og, O.init_positions(og), 100000)
+    rc, x1, st1 = hip.path_linear_sgd_raw(g, p)
+    s1, s2 = O.stress_1d(og, x1, 100000), O.stress_1d(og, x, 100000)
+    assert s1 < 0.05 * s0 and s2 < 0.05 * s0 and s2 < 1.5 * s1 + 1e-3, (s0, s1, s2)
