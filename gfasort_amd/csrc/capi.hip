@@ -19,8 +19,8 @@ hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool tr
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
-hipError_t launch_merge_prepare(const double *x, const double *x_prev, double *buf, uint64_t n, hipStream_t st);
-hipError_t launch_merge_apply(double *x, double *x_prev, const double *buf, uint64_t n, double scale_all, hipStream_t st);
+hipError_t launch_merge_prepare(const double *x, const double *x_prev, float *buf, uint64_t n, hipStream_t st);
+hipError_t launch_merge_apply(double *x, double *x_prev, const float *buf, uint64_t n, double scale_all, hipStream_t st);
 }
 
 static thread_local std::string g_err;
@@ -625,14 +625,14 @@ int gfs_ctx_trace(gfs_ctx *c, gfs_term *out, uint64_t n_terms, uint64_t *counts,
 }
 
 // ---- multi-GPU replica merge helpers (device pointers, asynchronous on hip_stream) -----------------
-int gfs_merge_prepare(const double *x, const double *x_prev, double *buf2n, uint64_t n, void *hip_stream) {
+int gfs_merge_prepare(const double *x, const double *x_prev, float *buf2n, uint64_t n, void *hip_stream) {
     if (!x || !x_prev || !buf2n) return fail(GFS_E_ARG, "null argument");
     if (n == 0) return GFS_OK;
     hipError_t e = gfs::launch_merge_prepare(x, x_prev, buf2n, n, (hipStream_t)hip_stream);
     if (e != hipSuccess) return fail(GFS_E_HIP, std::string("merge_prepare: ") + hipGetErrorString(e));
     return GFS_OK;
 }
-int gfs_merge_apply(double *x, double *x_prev, const double *buf2n, uint64_t n, double divide_all_by, void *hip_stream) {
+int gfs_merge_apply(double *x, double *x_prev, const float *buf2n, uint64_t n, double divide_all_by, void *hip_stream) {
     if (!x || !x_prev || !buf2n) return fail(GFS_E_ARG, "null argument");
     if (n == 0) return GFS_OK;
     hipError_t e = gfs::launch_merge_apply(x, x_prev, buf2n, n, divide_all_by, (hipStream_t)hip_stream);

@@ -179,38 +179,40 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
 // ------------------------------------------------------------------------------------------
 // Multi-GPU replica merge (no reference equivalent; gfasort_amd/distributed.py).  Two streaming
 // kernels around the one all-reduce of an iteration:
-//   prepare: buf[0][k] = x[k] - x_prev[k]  (this rank's batch),  buf[1][k] = delta != 0
+//   prepare: buf[0][k] = (float)(x[k] - x_prev[k])  (this rank's batch),  buf[1][k] = delta != 0
 //   apply  : x_prev[k] += sum_delta[k] / max(1, sum_touched[k]);  x[k] = x_prev[k]
-// 16 B per lane, grid-stride; pure HBM streaming.
+// The exchanged buffer is f32 (half the xGMI bytes; a delta is rounded to 24 bits, 6e-8 relative,
+// far below the SGD noise; all ranks apply the same reduced values, so replicas stay identical).
+// Grid-stride, pure HBM streaming.
 // ------------------------------------------------------------------------------------------
-__global__ void merge_prepare_kernel(const double *x, const double *x_prev, double *buf, uint64_t n) {
+__global__ void merge_prepare_kernel(const double *x, const double *x_prev, float *buf, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 2;
     for (uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; k < n; k += stride) {
         if (k + 1 < n) {
             const double2 a = *reinterpret_cast<const double2 *>(x + k), b = *reinterpret_cast<const double2 *>(x_prev + k);
-            double2 d = make_double2(a.x - b.x, a.y - b.y);
-            *reinterpret_cast<double2 *>(buf + k) = d;
-            *reinterpret_cast<double2 *>(buf + n + k) = make_double2(d.x != 0.0 ? 1.0 : 0.0, d.y != 0.0 ? 1.0 : 0.0);
+            const float d0 = (float)(a.x - b.x), d1 = (float)(a.y - b.y);
+            *reinterpret_cast<float2 *>(buf + k) = make_float2(d0, d1);
+            *reinterpret_cast<float2 *>(buf + n + k) = make_float2(d0 != 0.f ? 1.f : 0.f, d1 != 0.f ? 1.f : 0.f);
         } else {
-            double d = x[k] - x_prev[k];
-            buf[k] = d; buf[n + k] = d != 0.0 ? 1.0 : 0.0;
+            const float d = (float)(x[k] - x_prev[k]);
+            buf[k] = d; buf[n + k] = d != 0.f ? 1.f : 0.f;
         }
     }
 }
-__global__ void merge_apply_kernel(double *x, double *x_prev, const double *buf, uint64_t n, double scale_all) {
+__global__ void merge_apply_kernel(double *x, double *x_prev, const float *buf, uint64_t n, double scale_all) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        const double c = buf[n + k];
+        const double c = (double)buf[n + k];
         const double div = scale_all > 0.0 ? scale_all : (c > 1.0 ? c : 1.0);
-        const double v = x_prev[k] + buf[k] / div;
+        const double v = x_prev[k] + (double)buf[k] / div;
         x_prev[k] = v; x[k] = v;
     }
 }
-hipError_t launch_merge_prepare(const double *x, const double *x_prev, double *buf, uint64_t n, hipStream_t st) {
+hipError_t launch_merge_prepare(const double *x, const double *x_prev, float *buf, uint64_t n, hipStream_t st) {
     hipLaunchKernelGGL(merge_prepare_kernel, dim3(2048), dim3(256), 0, st, x, x_prev, buf, n);
     return hipGetLastError();
 }
-hipError_t launch_merge_apply(double *x, double *x_prev, const double *buf, uint64_t n, double scale_all, hipStream_t st) {
+hipError_t launch_merge_apply(double *x, double *x_prev, const float *buf, uint64_t n, double scale_all, hipStream_t st) {
     hipLaunchKernelGGL(merge_apply_kernel, dim3(2048), dim3(256), 0, st, x, x_prev, buf, n, scale_all);
     return hipGetLastError();
 }

@@ -7,7 +7,7 @@ the MI355X-native scale-out of it:
     step a only from its own steps; its share of an iteration's term updates is proportional
     to its share of the steps, so the global sampling distribution stays uniform over steps;
   * every rank runs its batch on its own replica of the positions, then the replicas are merged
-    with ONE all-reduce of [delta, touched] (delta_r = x_r - x_prev, touched_r = delta_r != 0):
+    with ONE all-reduce of [delta, touched] in f32 (delta_r = x_r - x_prev, touched_r = delta_r != 0):
         x <- x_prev + sum_r delta_r / max(1, sum_r touched_r)            (merge="touch", default)
     A node moved by one rank only receives that rank's full move; a node moved by c ranks
     receives the mean of the c proposals.  Plain summation (merge="sum") applies c full
@@ -128,7 +128,7 @@ class ShardedSGD:
             x = self.engine.positions
             n = x.shape[0]
             if self._buf is None:
-                self._buf = torch.empty((2, n), dtype=x.dtype, device=x.device)
+                self._buf = torch.empty((2, n), dtype=torch.float32, device=x.device)   # f32 on the wire
             buf = self._buf
             divide = {"touch": 0.0, "sum": 1.0, "mean": float(self.world)}[self.merge]
             if x.is_cuda and hasattr(self.engine, "hip"):
@@ -138,11 +138,11 @@ class ShardedSGD:
                 self.dist.all_reduce(buf)                 # RCCL over xGMI
                 self.engine.hip.merge_apply(x.data_ptr(), self.x_prev.data_ptr(), buf.data_ptr(), n, divide, st)
             else:
-                torch.sub(x, self.x_prev, out=buf[0])     # this rank's batch
-                buf[1] = (buf[0] != 0).to(x.dtype)
+                buf[0] = (x - self.x_prev).to(torch.float32)      # this rank's batch
+                buf[1] = (buf[0] != 0).to(torch.float32)
                 self.dist.all_reduce(buf)
-                div = buf[1].clamp_(min=1.0) if divide == 0.0 else divide
-                self.x_prev += buf[0] / div
+                div = buf[1].clamp(min=1.0).to(x.dtype) if divide == 0.0 else divide
+                self.x_prev += buf[0].to(x.dtype) / div
                 x.copy_(self.x_prev)
 
     def run(self):

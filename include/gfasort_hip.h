@@ -188,12 +188,12 @@ int   gfs_ctx_trace(gfs_ctx *ctx, gfs_term *out, uint64_t n_terms, uint64_t *cou
 
 /* ---- multi-GPU replica merge (device pointers; no reference equivalent) ----
  * One iteration on R ranks: every rank runs its batch on its replica x, then
- *   gfs_merge_prepare: buf[0..n) = x - x_prev, buf[n..2n) = (delta != 0)
+ *   gfs_merge_prepare: buf[0..n) = (float)(x - x_prev), buf[n..2n) = (delta != 0)   (f32: half the bytes)
  *   all-reduce(sum) of buf over the ranks (RCCL; the caller's collective)
  *   gfs_merge_apply  : x_prev += sum_delta / max(1, sum_touched)  (divide_all_by = 0), or
  *                      x_prev += sum_delta / divide_all_by         (1 = plain sum, R = mean); x = x_prev */
-int gfs_merge_prepare(const double *x, const double *x_prev, double *buf2n, uint64_t n, void *hip_stream);
-int gfs_merge_apply(double *x, double *x_prev, const double *buf2n, uint64_t n, double divide_all_by, void *hip_stream);
+int gfs_merge_prepare(const double *x, const double *x_prev, float *buf2n, uint64_t n, void *hip_stream);
+int gfs_merge_apply(double *x, double *x_prev, const float *buf2n, uint64_t n, double divide_all_by, void *hip_stream);
 
 #ifdef __cplusplus
 }
