@@ -74,7 +74,7 @@ def build_host(force=False, verbose=False):
         if force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
             cmd = [os.environ.get("CXX", "g++")] + CXX_FLAGS + ["-o", exe, os.path.join(HOST_DIR, main)] + \
                   [os.path.join(HOST_DIR, f) for f in HOST_SOURCES] + \
-                  ["-L" + LIBDIR, "-lgfasort_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
+                  ["-L" + LIBDIR, "-lgfasort_hip", "-pthread", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

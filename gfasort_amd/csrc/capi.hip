@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -76,6 +77,17 @@ int gfs_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int gfs_warmup(int device) {
+    // Creates the HIP context (the first HIP call of a process costs ~0.1-0.3 s); callers run this
+    // on a side thread while they are still parsing their input.
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(GFS_E_HIP, "no HIP device available (libgfasort_hip has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(GFS_E_ARG, "bad device index");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(nullptr));
+    return GFS_OK;
 }
 
 double gfs_fast_precise_pow(double a, double b) { return h_fpp(a, b); }
@@ -648,21 +660,32 @@ static int one_shot(const gfs_graph_view *g, const gfs_sgd_params *p, int dims, 
     if (g->n_nodes == 0) return GFS_NOTHING_TO_DO;                         // sgd.rs:242-244,780-782
     if (!x) return fail(GFS_E_ARG, "positions buffer is null");
     auto t0 = std::chrono::steady_clock::now();
+    const bool timing = std::getenv("GFS_TIMING") != nullptr;        // phase times of the one-shot call on stderr
+    auto lap = [&](const char *what) {
+        if (timing) std::fprintf(stderr, "[gfasort_hip] %-10s %8.2f ms\n", what,
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     gfs_ctx *c = nullptr;
     int rc = gfs_ctx_create(g, 0, &c);
     if (rc) return rc;
+    lap("ctx_create");
     if (dims == 0) rc = gfs_ctx_setup_1d(c, p, cfg, etas, zetas);
     else { gfs_layout_params lp; lp.dimensions = (uint64_t)dims; lp.sgd = *p; rc = gfs_ctx_setup_nd(c, &lp, cfg, etas, zetas); }
     if (rc) { gfs_ctx_destroy(c); return rc; }
+    lap("setup");
     if (dims == 0 && init_x) gfs_init_positions(g, x);
     rc = gfs_ctx_upload_positions(c, x, gfs_ctx_positions_len(c));
+    lap("upload");
     if (!rc) rc = gfs_ctx_run(c, nullptr);
+    lap("run");
     if (!rc) rc = gfs_ctx_download_positions(c, x, gfs_ctx_positions_len(c));
+    lap("download");
     if (!rc && stats) {
         rc = gfs_ctx_stats(c, stats);
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     gfs_ctx_destroy(c);
+    lap("destroy");
     return rc;
 }
 

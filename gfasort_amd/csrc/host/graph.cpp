@@ -2,6 +2,7 @@
 #include "graph.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <stdexcept>
 #include <unordered_map>
 
@@ -62,133 +63,169 @@ FlatGraph BidirectedGraph::flatten() const {
 
 void BidirectedGraph::apply_ordering(const std::vector<Handle> &ordering) {
     if (ordering.empty()) return;                                  // graph_ops.rs:1940
-    std::unordered_map<size_t, size_t> old_to_new;
-    for (size_t k = 0; k < ordering.size(); ++k) old_to_new[ordering[k].node_id()] = k + 1;   // 1-based
+    // old id -> new 1-based id (graph_ops.rs:1953-1957); a dense table instead of the reference's
+    // HashMap: ids outside it, or with 0, are "not in the ordering"
+    size_t max_old = nodes.size();
+    for (Handle h : ordering) max_old = std::max(max_old, h.node_id() + 1);
+    std::vector<size_t> old_to_new(max_old, 0);
+    for (size_t k = 0; k < ordering.size(); ++k) old_to_new[ordering[k].node_id()] = k + 1;
+    auto lookup = [&](size_t id) -> size_t { return id < old_to_new.size() ? old_to_new[id] : 0; };
     size_t max_new = 0;
-    for (auto &kv : old_to_new) max_new = std::max(max_new, kv.second);
+    for (size_t v : old_to_new) max_new = std::max(max_new, v);
     std::vector<std::optional<BiNode>> new_nodes(max_new + 1);
-    for (auto &kv : old_to_new) {
-        if (kv.first < nodes.size() && nodes[kv.first].has_value()) {
-            BiNode n = *nodes[kv.first];
-            n.id = kv.second;
-            n.rank = (uint64_t)(kv.second - 1);
-            new_nodes[kv.second] = std::move(n);
+    for (size_t id = 0; id < nodes.size(); ++id) {
+        size_t nid = lookup(id);
+        if (nid && nodes[id].has_value()) {
+            BiNode n = std::move(*nodes[id]);
+            n.id = nid;
+            n.rank = (uint64_t)(nid - 1);                          // 0-based rank
+            new_nodes[nid] = std::move(n);
         }
     }
     nodes = std::move(new_nodes);
     std::unordered_set<BiEdge, BiEdgeHash> new_edges;
+    new_edges.reserve(edges.size());
     for (const auto &e : edges) {
-        auto f = old_to_new.find(e.from.node_id()), t = old_to_new.find(e.to.node_id());
-        if (f != old_to_new.end() && t != old_to_new.end())
-            new_edges.insert(BiEdge{Handle::make(f->second, e.from.is_reverse()), Handle::make(t->second, e.to.is_reverse())});
+        size_t f = lookup(e.from.node_id()), t = lookup(e.to.node_id());
+        if (f && t) new_edges.insert(BiEdge{Handle::make(f, e.from.is_reverse()), Handle::make(t, e.to.is_reverse())});
     }
     edges = std::move(new_edges);
     for (auto &p : paths)
         for (auto &h : p.steps) {
-            auto it = old_to_new.find(h.node_id());
-            if (it != old_to_new.end()) h = Handle::make(it->second, h.is_reverse());
+            size_t nid = lookup(h.node_id());
+            if (nid) h = Handle::make(nid, h.is_reverse());
         }
     // node_order is NOT updated — exactly like the reference (it is written only by add_node).
 }
 
+namespace {
+inline void put_uint(std::string &b, uint64_t v) {
+    char tmp[24]; int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) b.push_back(tmp[--n]);
+}
+}  // namespace
+
 void BidirectedGraph::write_gfa(std::ostream &out) const {
-    out << "H\tVN:Z:1.0\n";
+    // one growing buffer, flushed in 8 MB pieces (the step lists of long paths are the bulk)
+    std::string b;
+    b.reserve(9u << 20);
+    auto flush = [&](bool force) { if (force || b.size() > (8u << 20)) { out.write(b.data(), (std::streamsize)b.size()); b.clear(); } };
+    b += "H\tVN:Z:1.0\n";
     for (size_t id = 0; id < nodes.size(); ++id)
-        if (nodes[id].has_value()) out << "S\t" << id << "\t" << nodes[id]->sequence << "\n";
-    std::vector<BiEdge> es(edges.begin(), edges.end());
-    std::sort(es.begin(), es.end(), [](const BiEdge &a, const BiEdge &b) {
-        return a.from.v != b.from.v ? a.from.v < b.from.v : a.to.v < b.to.v;
-    });
-    for (const auto &e : es)
-        out << "L\t" << e.from.node_id() << "\t" << e.from.orientation_char() << "\t" << e.to.node_id() << "\t"
-            << e.to.orientation_char() << "\t0M\n";
-    for (const auto &p : paths) {
-        out << "P\t" << p.name << "\t";
-        for (size_t k = 0; k < p.steps.size(); ++k) {
-            if (k) out << ",";
-            out << p.steps[k].node_id() << p.steps[k].orientation_char();
+        if (nodes[id].has_value()) {
+            b += "S\t"; put_uint(b, id); b.push_back('\t'); b += nodes[id]->sequence; b.push_back('\n');
+            flush(false);
         }
-        out << "\t*\n";
+    std::vector<BiEdge> es(edges.begin(), edges.end());
+    std::sort(es.begin(), es.end(), [](const BiEdge &a, const BiEdge &c) {
+        return a.from.v != c.from.v ? a.from.v < c.from.v : a.to.v < c.to.v;
+    });
+    for (const auto &e : es) {
+        b += "L\t"; put_uint(b, e.from.node_id()); b.push_back('\t'); b.push_back(e.from.orientation_char());
+        b.push_back('\t'); put_uint(b, e.to.node_id()); b.push_back('\t'); b.push_back(e.to.orientation_char());
+        b += "\t0M\n";
+        flush(false);
     }
+    for (const auto &p : paths) {
+        b += "P\t"; b += p.name; b.push_back('\t');
+        for (size_t k = 0; k < p.steps.size(); ++k) {
+            if (k) b.push_back(',');
+            put_uint(b, p.steps[k].node_id()); b.push_back(p.steps[k].orientation_char());
+            if ((k & 0xFFFF) == 0) flush(false);
+        }
+        b += "\t*\n";
+        flush(false);
+    }
+    flush(true);
 }
 
 // ---- parse_gfa ---------------------------------------------------------------------------------
-static std::vector<std::string> split(const std::string &s, char sep) {
-    std::vector<std::string> out;
-    size_t b = 0;
-    for (;;) {
-        size_t e = s.find(sep, b);
-        if (e == std::string::npos) { out.push_back(s.substr(b)); break; }
-        out.push_back(s.substr(b, e - b));
-        b = e + 1;
+// Field access without allocation: the k-th tab-separated field of a line.
+namespace {
+struct Line { const char *b, *e; };
+inline bool field(const Line &ln, int k, const char *&fb, const char *&fe) {
+    const char *p = ln.b;
+    for (int i = 0; i < k; ++i) {
+        const char *t = (const char *)memchr(p, '\t', (size_t)(ln.e - p));
+        if (!t) return false;
+        p = t + 1;
     }
-    return out;
+    const char *t = (const char *)memchr(p, '\t', (size_t)(ln.e - p));
+    fb = p; fe = t ? t : ln.e;
+    return true;
 }
-
-static size_t parse_usize(const std::string &s, const char *what) {
+inline int count_fields(const Line &ln) {
+    int n = 1;
+    for (const char *p = ln.b; (p = (const char *)memchr(p, '\t', (size_t)(ln.e - p))); ++p) ++n;
+    return n;
+}
+size_t parse_usize(const char *b, const char *e, const char *what) {
     // Rust `str::parse::<usize>`: optional '+', digits only, no whitespace, no overflow
-    size_t i = 0;
-    if (!s.empty() && s[0] == '+') i = 1;
-    if (i >= s.size()) throw std::runtime_error(std::string("Failed to parse ") + what + ": cannot parse integer from empty string");
+    if (b < e && *b == '+') ++b;
+    if (b >= e) throw std::runtime_error(std::string("Failed to parse ") + what + ": cannot parse integer from empty string");
     uint64_t v = 0;
-    for (; i < s.size(); ++i) {
-        if (s[i] < '0' || s[i] > '9') throw std::runtime_error(std::string("Failed to parse ") + what + ": invalid digit found in string");
-        uint64_t nv = v * 10 + (uint64_t)(s[i] - '0');
+    for (; b < e; ++b) {
+        if (*b < '0' || *b > '9') throw std::runtime_error(std::string("Failed to parse ") + what + ": invalid digit found in string");
+        uint64_t nv = v * 10 + (uint64_t)(*b - '0');
         if (nv / 10 != v) throw std::runtime_error(std::string("Failed to parse ") + what + ": number too large to fit in target type");
         v = nv;
     }
     return (size_t)v;
 }
-
-static std::string trim(const std::string &s) {
-    size_t b = 0, e = s.size();
-    while (b < e && isspace((unsigned char)s[b])) ++b;
-    while (e > b && isspace((unsigned char)s[e - 1])) --e;
-    return s.substr(b, e - b);
-}
+}  // namespace
 
 BidirectedGraph parse_gfa(const std::string &content) {
     BidirectedGraph g;
-    std::vector<std::string> lines;
+    // str::lines(): split on '\n', strip one trailing '\r', no final empty line
+    std::vector<Line> lines;
     {
-        size_t b = 0;
-        while (b <= content.size()) {
-            size_t e = content.find('\n', b);
-            std::string ln = content.substr(b, e == std::string::npos ? std::string::npos : e - b);
-            if (!ln.empty() && ln.back() == '\r') ln.pop_back();   // str::lines strips \r\n
-            if (e == std::string::npos) { if (!ln.empty()) lines.push_back(ln); break; }
+        const char *p = content.data(), *end = p + content.size();
+        while (p < end) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *le = nl ? nl : end;
+            Line ln{p, (le > p && le[-1] == '\r') ? le - 1 : le};
             lines.push_back(ln);
-            b = e + 1;
+            if (!nl) break;
+            p = nl + 1;
         }
     }
-    for (const auto &ln : lines)                                   // pass 1: S
-        if (!ln.empty() && ln[0] == 'S') {
-            auto parts = split(ln, '\t');
-            if (parts.size() >= 3) g.add_node(parse_usize(parts[1], "node ID"), parts[2]);
+    const char *fb = nullptr, *fe = nullptr;
+    for (const Line &ln : lines)                                   // pass 1: S (gfasort.rs:93-103)
+        if (ln.b < ln.e && *ln.b == 'S' && count_fields(ln) >= 3) {
+            field(ln, 1, fb, fe);
+            size_t id = parse_usize(fb, fe, "node ID");
+            field(ln, 2, fb, fe);
+            g.add_node(id, std::string(fb, fe));
         }
-    for (const auto &ln : lines)                                   // pass 2: L
-        if (!ln.empty() && ln[0] == 'L') {
-            auto parts = split(ln, '\t');
-            if (parts.size() >= 5) {
-                size_t f = parse_usize(parts[1], "from ID"), t = parse_usize(parts[3], "to ID");
-                g.add_edge(parts[2] == "+" ? Handle::forward(f) : Handle::reverse(f),
-                           parts[4] == "+" ? Handle::forward(t) : Handle::reverse(t));
-            }
+    for (const Line &ln : lines)                                   // pass 2: L (gfasort.rs:106-132)
+        if (ln.b < ln.e && *ln.b == 'L' && count_fields(ln) >= 5) {
+            field(ln, 1, fb, fe); size_t f = parse_usize(fb, fe, "from ID");
+            field(ln, 2, fb, fe); bool ff = (fe - fb == 1 && *fb == '+');
+            field(ln, 3, fb, fe); size_t t = parse_usize(fb, fe, "to ID");
+            field(ln, 4, fb, fe); bool tf = (fe - fb == 1 && *fb == '+');
+            g.add_edge(ff ? Handle::forward(f) : Handle::reverse(f), tf ? Handle::forward(t) : Handle::reverse(t));
         }
-    for (const auto &ln : lines)                                   // pass 3: P
-        if (!ln.empty() && ln[0] == 'P') {
-            auto parts = split(ln, '\t');
-            if (parts.size() >= 3) {
-                BiPath p; p.name = parts[1];
-                for (const auto &raw : split(parts[2], ',')) {
-                    std::string s = trim(raw);
-                    if (s.empty()) continue;
-                    char orient = s.back();
-                    size_t id = parse_usize(s.substr(0, s.size() - 1), "path node ID");
+    for (const Line &ln : lines)                                   // pass 3: P (gfasort.rs:135-163)
+        if (ln.b < ln.e && *ln.b == 'P' && count_fields(ln) >= 3) {
+            BiPath p;
+            field(ln, 1, fb, fe); p.name.assign(fb, fe);
+            field(ln, 2, fb, fe);
+            const char *q = fb;
+            while (q <= fe) {
+                const char *c = (const char *)memchr(q, ',', (size_t)(fe - q));
+                const char *sb = q, *se = c ? c : fe;
+                while (sb < se && isspace((unsigned char)*sb)) ++sb;   // step_str.trim()
+                while (se > sb && isspace((unsigned char)se[-1])) --se;
+                if (sb < se) {
+                    char orient = se[-1];
+                    size_t id = parse_usize(sb, se - 1, "path node ID");
                     p.steps.push_back(orient == '+' ? Handle::forward(id) : Handle::reverse(id));
                 }
-                g.paths.push_back(std::move(p));
+                if (!c) break;
+                q = c + 1;
             }
+            g.paths.push_back(std::move(p));
         }
     return g;
 }

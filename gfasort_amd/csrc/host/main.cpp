@@ -8,6 +8,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 
 #include "sgd.hpp"
 
@@ -79,6 +80,9 @@ int main(int argc, char **argv) {
     auto t_start = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     double t_read = 0, t_parse = 0, t_steps = 0, t_write = 0;
+    // bring the HIP context up while the GFA is read and parsed (errors surface later, in the SGD call)
+    std::thread warm([] { (void)gfs_warmup(0); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
     if (args.verbose >= 1) std::cerr << "[gfasort] reading " << args.input << "\n";
     std::string content;
     {
@@ -107,6 +111,7 @@ int main(int argc, char **argv) {
 
     bool have_layout = false;
     Layout layout;
+    if (warm.joinable()) warm.join();
     auto t_s0 = std::chrono::steady_clock::now();
     try {
         size_t step = 0;

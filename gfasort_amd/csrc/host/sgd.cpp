@@ -131,40 +131,46 @@ static void check(int rc) {
     if (rc < 0) throw std::runtime_error(std::string("gfasort_hip: ") + gfs_last_error());
 }
 
-std::unordered_map<size_t, double> path_linear_sgd(const BidirectedGraph &g, const PathSGDParams &p,
-                                                   const HipOptions &opt, gfs_stats *stats) {
-    std::unordered_map<size_t, double> positions;
-    if (g.node_count() == 0) return positions;                       // sgd.rs:242-244
-    FlatGraph f = g.flatten();
+// positions by dense index; empty when the reference returns an empty map
+static std::vector<double> path_linear_sgd_vec(const BidirectedGraph &g, const FlatGraph &f, const PathSGDParams &p,
+                                               const HipOptions &opt, gfs_stats *stats) {
+    std::vector<double> x;
+    if (g.node_count() == 0) return x;                               // sgd.rs:242-244
     gfs_graph_view v = f.view();
     gfs_sgd_params cp = p.to_c();
-    std::vector<double> x(f.node_len.size());
+    x.resize(f.node_len.size());
     gfs_stats st;
     int rc = gfs_path_linear_sgd(&v, &cp, &opt.cfg, nullptr, nullptr, 1, x.data(), &st);
     check(rc);
     if (stats) *stats = st;
     if (rc == GFS_NOTHING_TO_DO) {
         std::cerr << "[path_sgd] No paths with multiple steps found\n";   // sgd.rs:259
-        return positions;
+        x.clear();
     }
+    return x;
+}
+
+std::unordered_map<size_t, double> path_linear_sgd(const BidirectedGraph &g, const PathSGDParams &p,
+                                                   const HipOptions &opt, gfs_stats *stats) {
+    std::unordered_map<size_t, double> positions;
+    FlatGraph f = g.flatten();
+    std::vector<double> x = path_linear_sgd_vec(g, f, p, opt, stats);
     positions.reserve(x.size());
-    for (size_t i = 0; i < x.size(); ++i) positions.emplace(i, x[i]);
+    for (size_t i = 0; i < x.size(); ++i) positions.emplace(i, x[i]);       // sgd.rs:604-607
     return positions;
 }
 
 std::vector<Handle> path_sgd_sort(const BidirectedGraph &g, const PathSGDParams &p, const HipOptions &opt,
                                   gfs_stats *stats) {
-    auto positions = path_linear_sgd(g, p, opt, stats);
+    // same result as sorting path_linear_sgd's map (sgd.rs:641-672), without materialising the map
+    FlatGraph f = g.flatten();
+    std::vector<double> x = path_linear_sgd_vec(g, f, p, opt, stats);
     std::vector<Handle> out;
-    if (positions.empty()) return out;
-    std::vector<size_t> ids;                                         // idx -> handle, sgd.rs:649-662
-    for (size_t id : g.seeding_order()) if (id < g.nodes.size() && g.nodes[id].has_value()) ids.push_back(id);
-    std::vector<double> x(positions.size());
-    for (auto &kv : positions) x[kv.first] = kv.second;
+    if (x.empty()) return out;
     std::vector<uint64_t> order(x.size());
     check(gfs_sort_order(x.data(), x.size(), order.data()));         // sgd.rs:665-666
     out.reserve(order.size());
-    for (uint64_t idx : order) if (idx < ids.size()) out.push_back(Handle::forward(ids[idx]));
+    for (uint64_t idx : order) out.push_back(Handle::forward(f.node_ids[idx]));   // idx -> handle, sgd.rs:649-662
     return out;
 }
 

@@ -143,9 +143,15 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
             }
             wave_done += nvalid < remaining ? nvalid : remaining;
             double xi = 0.0, xj = 0.0;
-            if (valid) { xi = load_pos<ATOMIC_LOADS>(x + i); xj = load_pos<ATOMIC_LOADS>(x + j); }   // :541-542
+            if (valid) {
+                if (a.dbg & 2u) { xi = (double)i; xj = (double)j; }                    // ablation: no position loads
+                else { xi = load_pos<ATOMIC_LOADS>(x + i); xj = load_pos<ATOMIC_LOADS>(x + j); }   // :541-542
+            }
             if (DEFER) {
-                if (pend) { add_pos(x + pend_i, -pend_r); add_pos(x + pend_j, pend_r); }   // trip t-1's :575-576
+                if (pend) {
+                    if (a.dbg & 1u) { asm volatile("" :: "v"(pend_r), "v"(pend_i), "v"(pend_j)); }   // ablation: no atomics
+                    else { add_pos(x + pend_i, -pend_r); add_pos(x + pend_j, pend_r); }   // trip t-1's :575-576
+                }
                 pend = valid;
             }
             if (valid) {

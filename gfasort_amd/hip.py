@@ -60,7 +60,7 @@ TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)
 
 # every symbol include/gfasort_hip.h declares
 EXPORTS = [
-    "gfs_version", "gfs_last_error", "gfs_device_count", "gfs_fast_precise_pow", "gfs_sgd_schedule",
+    "gfs_version", "gfs_last_error", "gfs_device_count", "gfs_warmup", "gfs_fast_precise_pow", "gfs_sgd_schedule",
     "gfs_zeta_table_len", "gfs_zeta_table", "gfs_init_positions", "gfs_init_layout_dim0",
     "gfs_sort_order", "gfs_path_linear_sgd", "gfs_path_linear_sgd_layout", "gfs_ctx_create",
     "gfs_ctx_create_with_layout", "gfs_ctx_node_layout",

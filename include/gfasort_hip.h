@@ -127,6 +127,8 @@ typedef struct gfs_ctx gfs_ctx;
 const char *gfs_version(void);
 const char *gfs_last_error(void);
 int         gfs_device_count(void);
+/* optional: create the HIP context now (e.g. on a side thread while the caller parses its input) */
+int         gfs_warmup(int device);
 
 /* ---- host tables, bit-exact restatements (no device needed) ---- */
 /* fast_precise_pow                                                        sgd.rs:155-182 */

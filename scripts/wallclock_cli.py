@@ -26,7 +26,7 @@ def main():
         r = subprocess.run([B.CLI, "-i", src, "-o", dst, "-p", "Y", "--iter-max", "200", "-v", "1"] + extra, capture_output=True, text=True)
         dt = time.time() - t0
         print(" ".join(extra), "rc", r.returncode, f"wall {dt:.2f}s")
-        print("\n".join(l for l in r.stderr.split("\n") if "gfasort_hip" in l or "done" in l))
+        print("\n".join(l for l in r.stderr.split("\n") if "gfasort_hip" in l or "done" in l or "ms" in l))
     g2 = G.load_gfa(dst) if os.path.getsize(dst) < 4e8 else None
 
 if __name__ == "__main__":
