@@ -91,7 +91,9 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                 valid = rank < remaining;
             }
             wave_done += nvalid < remaining ? nvalid : remaining;
-            double upd_r0 = 0.0, upd_r1 = 0.0; double *upd_ci = a.x, *upd_cj = a.x; bool upd_i = false, upd_j = false;
+            double upd_r[D]; double *upd_ci = a.x, *upd_cj = a.x; bool upd_i = false, upd_j = false;
+#pragma unroll
+            for (int d = 0; d < D; ++d) upd_r[d] = 0.0;
             if (valid) {
                 double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                   // :1085-1086
                 double *ci = a.x + idx_i * D, *cj = a.x + idx_j * D;
@@ -107,7 +109,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                 double delta = mu * (mag - term_dist) / 2.0;                           // :1125
                 double r = delta / mag;                                                // :1142
                 const bool same = idx_i == idx_j;
-                if (D != 2) {
+                if (D < 2) {
 #pragma unroll
                     for (int d = 0; d < D; ++d) {                                      // :1143-1149
                         double r_d = r * deltas[d];
@@ -115,7 +117,8 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                         add_pos(cj + d, r_d);
                     }
                 } else {
-                    upd_r0 = r * deltas[0]; upd_r1 = r * deltas[D > 1 ? 1 : 0];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) upd_r[d] = r * deltas[d];
                     upd_ci = ci; upd_cj = cj; upd_i = !same; upd_j = true;
                 }
                 ++done;                                                                // :1151
@@ -127,23 +130,27 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                     }
                 }
             }
-            if (D == 2) {
-                // D = 2: the two coordinates of an end are adjacent (16 B).  Re-deal the 64 lanes' adds so
-                // that lanes 2m and 2m+1 of one instruction carry dim 0 and dim 1 of the SAME end: the
-                // hardware merges them (and the neighbouring nodes of the run) into one 64-B request, which
-                // halves the fabric atomics of the layout kernel.  Wave-uniform control flow: all lanes
-                // take part in the shuffles.
-                const int d = lane & 1;
+            if (D >= 2) {
+                // The D coordinates of an end are adjacent (8*D bytes).  Re-deal the 64 lanes' adds so that
+                // a group of P = 2 (D=2) or 4 (D=3) adjacent lanes of one instruction carries the D
+                // coordinates of the SAME end: the hardware merges them (and the neighbouring nodes of the
+                // run) into one 64-B request, which cuts the fabric atomics of the layout kernel by D.
+                // Wave-uniform control flow: all lanes take part in the shuffles.
+                constexpr int P = D <= 2 ? 2 : 4;
+                const int d = lane & (P - 1);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int m = half * 32 + (lane >> 1);
-                    const double r0 = __shfl(upd_r0, m, 64), r1 = __shfl(upd_r1, m, 64);
+                for (int pass = 0; pass < P; ++pass) {
+                    const int m = pass * (64 / P) + lane / P;
+                    double v = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { const double rk = __shfl(upd_r[k], m, 64); if (k == d) v = rk; }
                     const unsigned long long pi = __shfl((unsigned long long)upd_ci, m, 64);
                     const unsigned long long pj = __shfl((unsigned long long)upd_cj, m, 64);
                     const int fi = __shfl((int)upd_i, m, 64), fj = __shfl((int)upd_j, m, 64);
-                    const double v = d ? r1 : r0;
-                    if (fi) add_pos(reinterpret_cast<double *>(pi) + d, -v);
-                    if (fj) add_pos(reinterpret_cast<double *>(pj) + d, v);
+                    if (d < D) {
+                        if (fi) add_pos(reinterpret_cast<double *>(pi) + d, -v);
+                        if (fj) add_pos(reinterpret_cast<double *>(pj) + d, v);
+                    }
                 }
             }
             if (wave_done >= wave_quota) break;
