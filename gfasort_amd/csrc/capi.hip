@@ -294,9 +294,12 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
         // updates per stream per batch on small graphs.
         uint64_t chip = (uint64_t)c->cu_count * 512;
         uint64_t want = (c->quota_total + 7) / 8;
-        // and never more than ~2 terms in flight per node: Hogwild staleness grows with
-        // streams / nodes (a 26k-node graph under 131072 streams lost 50 % layout quality)
-        uint64_t by_nodes = std::max<uint64_t>(64, (2 * c->n_nodes + 63) / 64 * 64);
+        // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every
+        // in-flight term corrects its two nodes from positions read before the others landed, so
+        // with ~2 concurrent terms per node and mu clamped at 1 the corrections overshoot — a
+        // 6000-node graph of short paths diverged (stress 1e8) under 6784 streams and converges
+        // under 1024 (profiles/r01/stream_cap_probe.log).  Explicit n_streams overrides this.
+        uint64_t by_nodes = std::max<uint64_t>(64, (c->n_nodes / 4) / 64 * 64);
         T = std::max<uint64_t>(64, std::min<uint64_t>(std::min(chip, by_nodes), (want + 63) / 64 * 64));
     }
     if (T > 0x7FFFFFFFull) return fail(GFS_E_ARG, "n_streams too large");

@@ -52,16 +52,18 @@ def _parse_out(path):
 
 
 @pytest.mark.gpu
-def test_cli_sort_replay_matches_oracle_order(bins, tmp_path):
-    """`-p Y --iter-max 10 --streams 1`: the written GFA equals apply_ordering(oracle order)."""
-    src = os.path.join(DATA, "DRB1-3123.gfa")
+@pytest.mark.parametrize("name,iters", [("simple.gfa", 100), ("lil.gfa", 100), ("DRB1-3123.gfa", 10)])
+def test_cli_sort_replay_matches_oracle_order(bins, tmp_path, name, iters):
+    """BASELINE configs[0] plumbing: `-p Y --iter-max N --streams 1` on the reference's fixtures — the
+    written GFA equals apply_ordering(oracle order)."""
+    src = os.path.join(DATA, name)
     o = str(tmp_path / "sorted.gfa")
-    r = subprocess.run([bins[0], "-i", src, "-o", o, "-p", "Y", "--iter-max", "10", "--streams", "1", "-v", "1"],
+    r = subprocess.run([bins[0], "-i", src, "-o", o, "-p", "Y", "--iter-max", str(iters), "--streams", "1", "-v", "1"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
-    g = load("DRB1-3123.gfa")
+    g = load(name)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
-    p.iter_max = 10
+    p.iter_max = iters
     og = oracle_graph(g)
     x = O.init_positions(og)
     O.sgd_1d(og, oracle_params(p), x, n_streams=1)
@@ -71,7 +73,7 @@ def test_cli_sort_replay_matches_oracle_order(bins, tmp_path):
     wl, gl = want.split("\n"), got.split("\n")
     assert [l for l in gl if l[:1] in "HSP"] == [l for l in wl if l[:1] in "HSP"]
     assert sorted(l for l in gl if l[:1] == "L") == sorted(l for l in wl if l[:1] == "L")
-    assert "385649 term updates" in r.stderr
+    assert f"{(iters + 1) * p.min_term_updates} term updates" in r.stderr
 
 
 @pytest.mark.gpu

@@ -455,3 +455,81 @@ def test_two_ranks_on_one_gpu_hip_engine():
     rc, x1, st1 = hip.path_linear_sgd_raw(g, p)
     s1, s2 = O.stress_1d(og, x1, 100000), O.stress_1d(og, x, 100000)
     assert s1 < 0.05 * s0 and s2 < 0.05 * s0 and s2 < 1.5 * s1 + 1e-3, (s0, s1, s2)
+
+
+# ---- kernels must terminate when every sampled term is rejected ----------------------------------------
+@pytest.mark.parametrize("bundle", [1, 16, 64])
+def test_all_terms_rejected_terminates(bundle):
+    """All nodes have length 0 => every term_dist is 0 => the reference would spin forever
+    (sgd.rs:514-516 `continue`); here every stream / wave gives up after its attempt bound and the
+    call returns with zero updates and unchanged positions."""
+    n = 4096
+    g = G.FlatGraph(node_len=np.zeros(n, dtype=np.uint32), step_node=np.arange(n, dtype=np.uint32),
+                    step_is_rev=np.zeros(n, dtype=np.uint8), path_first_step=np.array([0, n], dtype=np.uint64),
+                    node_ids=np.arange(1, n + 1, dtype=np.uint64), path_names=["p"])
+    p = P.PathSGDParams(iter_max=2, min_term_updates=n, eta_max=float(n * n), space=1, space_max=100)
+    x0 = np.arange(n, dtype=np.float64)
+    rc, x, st = hip.path_linear_sgd_raw(g, p, x=x0.copy(), cfg=hip.make_config(n_streams=256, attempt_factor=2,
+                                                                               flags=hip.F_BUNDLE(bundle)))
+    assert rc == 0 and st.term_updates == 0 and st.attempts > 0 and np.array_equal(x, x0)
+
+
+# ---- the Python host mirror (gfasort_amd.sgd) on the GPU ---------------------------------------------------
+def test_python_host_mirror_entry_points():
+    from gfasort_amd import sgd as S
+    from gfasort_amd.layout import Layout
+    g = G.synth_chain(20000, 4)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    x = S.path_linear_sgd(g, p)
+    assert x.shape[0] == g.n_nodes and np.isfinite(x).all()
+    order = S.sgd_sort_only(g, p)
+    ids = g.node_ids[order.astype(np.int64)].astype(np.int64)
+    assert np.array_equal(ids, np.arange(1, 20001)) or np.array_equal(ids, np.arange(20000, 0, -1))
+    o2n = G.apply_ordering_ids(g, order)
+    assert sorted(o2n.values()) == list(range(1, 20001))
+    lay, st = S.path_linear_sgd_layout(g, P.LayoutSGDParams.from_graph(g, 2, 1), return_stats=True)
+    assert isinstance(lay, Layout) and (lay.dimensions, lay.num_nodes) == (2, 20000)
+    assert st.term_updates == 31 * 10 * g.n_steps
+    s = O.layout_stress(oracle_graph(g), 2, lay.coords, 50000)
+    assert s < 0.05
+    # TSV round trip of a real layout
+    import io
+    back = Layout.read_tsv(io.StringIO(lay.to_tsv()))
+    assert np.array_equal(back.coords, lay.coords)
+    # empty graph: the reference's early returns (sgd.rs:242-244, 780-782)
+    g0 = G.parse_gfa("H\tVN:Z:1.0\n")
+    assert S.path_linear_sgd(g0, P.PathSGDParams()).shape[0] == 0
+    assert S.path_linear_sgd_layout(g0, P.LayoutSGDParams()).num_nodes == 0
+
+
+def test_reverse_steps_and_short_paths_mix():
+    """Paths with reverse-orientation steps and a crowd of short paths next to one long path: the
+    auto policy keeps reference streams (most steps are in short paths), results stay finite, and an
+    explicit bundle still works (short paths are handled by the leader alone)."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    lens = rng.integers(1, 9, n).astype(np.uint32)
+    long_path = np.arange(n, dtype=np.uint32)
+    shorts = [np.arange(s, s + 12, dtype=np.uint32) for s in rng.integers(0, n - 12, 4000)]
+    steps = np.concatenate([long_path] + shorts)
+    firsts = np.concatenate([[0], np.cumsum([len(long_path)] + [12] * len(shorts))]).astype(np.uint64)
+    rev = (rng.random(steps.shape[0]) < 0.3).astype(np.uint8)
+    g = G.FlatGraph(node_len=lens, step_node=steps, step_is_rev=rev, path_first_step=firsts,
+                    node_ids=np.arange(1, n + 1, dtype=np.uint64), path_names=[f"p{k}" for k in range(len(shorts) + 1)])
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 30
+    og = oracle_graph(g)
+    s0 = O.stress_1d(og, np.asarray(rng.permutation(n), dtype=np.float64) * 4.5, 50000)
+    for b in (0, 8):
+        rc, x, st = hip.path_linear_sgd_raw(g, p, x=np.asarray(rng.permutation(n), dtype=np.float64) * 4.5,
+                                            cfg=hip.make_config(flags=hip.F_BUNDLE(b)))
+        assert rc == 0 and st.term_updates == 31 * p.min_term_updates and np.isfinite(x).all()
+        assert st.bundle == (1 if b == 0 else 8)
+        assert O.stress_1d(og, x, 50000) < 0.2 * s0
+    lp = P.LayoutSGDParams.from_graph(g, 2, 1)
+    lp.iter_max = 10
+    c0 = gaussian_init(g, 2, 3)
+    c_ref = c0.copy()
+    O.sgd_nd(og, oracle_params(lp), c_ref, n_streams=1)
+    rc, c, st = hip.path_linear_sgd_layout_raw(g, lp, c0, cfg=hip.make_config(n_streams=1))
+    assert np.array_equal(c.view(np.uint64), c_ref.view(np.uint64))     # reverse steps: end selection bit-exact
