@@ -193,6 +193,7 @@ struct gfs_ctx {
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    double kernel_ms_harvested = 0.0;  // durations of event pairs already recycled
     uint64_t iterations = 0;
     double total_ms = 0.0;
 };
@@ -219,7 +220,7 @@ static int seed_streams(gfs_ctx *c) {
     HIPCHK(hipMemcpy(c->d_rng, st.data(), st.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long)));
     if (c->d_trace_cnt) HIPCHK(hipMemset(c->d_trace_cnt, 0, T * sizeof(uint32_t)));
-    c->events_used = 0; c->iterations = 0; c->total_ms = 0.0;
+    c->events_used = 0; c->kernel_ms_harvested = 0.0; c->iterations = 0; c->total_ms = 0.0;
     return GFS_OK;
 }
 
@@ -559,9 +560,19 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     iter_consts(c, k, a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
     if (c->events_used == c->events.size()) {
-        hipEvent_t e0, e1;
-        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-        c->events.emplace_back(e0, e1);
+        if (c->events.size() >= 4096) {
+            // long-lived context: recycle the pool instead of growing it (one sync per 4096 launches)
+            HIPCHK(hipEventSynchronize(c->events.back().second));
+            for (auto &p : c->events) {
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) c->kernel_ms_harvested += t;
+            }
+            c->events_used = 0;
+        } else {
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            c->events.emplace_back(e0, e1);
+        }
     }
     auto &ev = c->events[c->events_used++];
     HIPCHK(hipEventRecord(ev.first, st));
@@ -606,7 +617,7 @@ int gfs_ctx_stats(gfs_ctx *c, gfs_stats *out) {
     HIPCHK(hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
     out->term_updates = cnt[0]; out->attempts = cnt[1];
     out->iterations = c->iterations; out->n_streams = c->n_streams; out->bundle = c->bundle;
-    double ms = 0.0;
+    double ms = c->kernel_ms_harvested;
     for (size_t k = 0; k < c->events_used; ++k) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, c->events[k].first, c->events[k].second) == hipSuccess) ms += t;

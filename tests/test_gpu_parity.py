@@ -533,3 +533,36 @@ def test_reverse_steps_and_short_paths_mix():
     O.sgd_nd(og, oracle_params(lp), c_ref, n_streams=1)
     rc, c, st = hip.path_linear_sgd_layout_raw(g, lp, c0, cfg=hip.make_config(n_streams=1))
     assert np.array_equal(c.view(np.uint64), c_ref.view(np.uint64))     # reverse steps: end selection bit-exact
+
+
+def test_rank_agreement_with_oracle_on_drb1():
+    """P2 on a bubble-rich real graph: the GPU order and the oracle order agree as rankings
+    (Spearman >= 0.99, after orienting both the same way — a 1D layout is reflection-invariant)."""
+    g = load("DRB1-3123.gfa")
+    p = _ygs(g, 100)
+    og = oracle_graph(g)
+    x_ref = O.init_positions(og)
+    O.sgd_1d(og, oracle_params(p), x_ref, n_streams=8)
+    rc, x, st = hip.path_linear_sgd_raw(g, p)
+
+    def ranks(v):
+        r = np.empty(v.shape[0]); r[np.argsort(v, kind="stable")] = np.arange(v.shape[0]); return r
+    ra, rb = ranks(x_ref), ranks(x)
+    rho = np.corrcoef(ra, rb)[0, 1]
+    assert abs(rho) >= 0.99, rho
+    # both keep the input's orientation here (the input order seeds the positions)
+    assert rho > 0
+
+
+def test_many_launches_recycle_event_pool():
+    g = load("lil.gfa")
+    p = _ygs(g, 100)
+    ctx = hip.Context(g)
+    ctx.setup_1d(p, hip.make_config(n_streams=64))
+    ctx.upload(hip.init_positions(g))
+    for rep in range(50):                     # 5050 launches > the 4096-pair pool
+        for k in range(101):
+            ctx.run_iteration(k)
+    st = ctx.stats()
+    assert st.iterations == 5050 and st.term_updates == 5050 * p.min_term_updates and st.kernel_ms > 0
+    ctx.close()
