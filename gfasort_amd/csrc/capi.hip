@@ -20,6 +20,11 @@ hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool tr
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
+                                   const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
+                                   uint64_t n_steps, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len);
+hipError_t sort_order_device(const double *d_x_layout, const uint32_t *d_perm, uint64_t n, uint64_t stride_doubles,
+                             void *d_tmp, uint32_t **d_order_out);
 hipError_t launch_merge_prepare(const double *x, const double *x_prev, float *buf, uint64_t n, hipStream_t st);
 hipError_t launch_merge_apply(double *x, double *x_prev, const float *buf, uint64_t n, double scale_all, hipStream_t st);
 }
@@ -152,8 +157,15 @@ int gfs_init_layout_dim0(const gfs_graph_view *g, uint64_t D, double *c) { // sg
 int gfs_sort_order(const double *x, uint64_t n, uint64_t *order) {         // sgd.rs:665-671
     if ((!x || !order) && n) return fail(GFS_E_ARG, "null argument");
     std::iota(order, order + n, (uint64_t)0);
-    // partial_cmp(..).unwrap_or(Equal): a NaN compares Equal to everything; stable; ties by idx
-    std::stable_sort(order, order + n, [x](uint64_t a, uint64_t b) { return x[a] < x[b]; });
+    // partial_cmp(..).unwrap_or(Equal) + stable sort: ascending, -0.0 == +0.0, ties keep the index
+    // order.  NaNs (never produced by a finite run) are placed after all numbers so that the order
+    // is total; the device version (gfs_ctx_sort_order) uses the same rule.
+    std::stable_sort(order, order + n, [x](uint64_t a, uint64_t b) {
+        const double xa = x[a], xb = x[b];
+        if (xa != xa) return false;
+        if (xb != xb) return true;
+        return xa < xb;
+    });
     return GFS_OK;
 }
 
@@ -174,6 +186,7 @@ struct gfs_ctx {
     uint4 *d_step_rec = nullptr;
     uint4 *d_path_rec = nullptr;
     uint64_t *d_path_len = nullptr;
+    uint32_t *d_perm = nullptr;         // node layout on the device (dense index -> slot)
     // SGD state
     int dims = 0;                      // 0 = 1D
     bool configured = false;
@@ -422,40 +435,54 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
         for (uint64_t k = 0; k < g->n_nodes; ++k) if (c->perm[k] == 0xFFFFFFFFu) c->perm[k] = next++;
     }
 
-    // PathIndex::from_graph (sgd.rs:34-71) into 16-byte records
-    std::vector<uint4> rec(std::max<uint64_t>(g->n_steps, 1));
+    // Path records (host, P entries) and the facts the launch logic needs
     std::vector<uint4> prec(std::max<uint64_t>(g->n_paths, 1));
-    std::vector<uint64_t> plen(std::max<uint64_t>(g->n_paths, 1));
     for (uint64_t p = 0; p < g->n_paths; ++p) {
         uint64_t b = g->path_first_step[p], e = g->path_first_step[p + 1];
-        uint64_t position = 0;
-        for (uint64_t s = b; s < e; ++s) {
-            uint32_t n = g->step_node[s];
-            rec[s].x = n == GFS_NO_NODE ? GFS_NO_NODE : c->perm[n];
-            rec[s].y = (uint32_t)p | ((uint32_t)(g->step_is_rev[s] & 1) << 31);
-            rec[s].z = (uint32_t)position; rec[s].w = (uint32_t)(position >> 32);
-            if (n != GFS_NO_NODE) position += g->node_len[n];
-        }
         uint32_t cnt = (uint32_t)(e - b);
         prec[p].x = (uint32_t)b; prec[p].y = cnt;
         prec[p].z = cnt ? (uint32_t)(0u - cnt) % cnt : 0u; prec[p].w = 0;
-        plen[p] = position;
         c->path_counts.push_back(cnt);
         if (cnt > 1) c->valid_paths = true;                               // sgd.rs:250-256
         c->max_path_steps = std::max(c->max_path_steps, cnt);
     }
+    // K3 on the device: PathIndex::from_graph (sgd.rs:34-71) — the per-path exclusive prefix sum of
+    // node lengths over the steps — written straight into the 16-byte step records
+    // (index_kernels.hip).  Uploads 5 B per step instead of 16.
     auto bail = [&](const char *what, hipError_t e) {
         std::string m = std::string(what) + ": " + hipGetErrorString(e);
         gfs_ctx_destroy(c);
         return fail(GFS_E_HIP, m);
     };
+    const uint64_t S = g->n_steps, N = g->n_nodes, P = g->n_paths;
+    uint32_t *d_step_node = nullptr, *d_node_len = nullptr; uint8_t *d_rev = nullptr; uint64_t *d_first = nullptr, *d_tmp = nullptr;
+    auto free_tmp = [&]() {
+        if (d_step_node) (void)hipFree(d_step_node); if (d_node_len) (void)hipFree(d_node_len);
+        if (d_rev) (void)hipFree(d_rev); if (d_first) (void)hipFree(d_first); if (d_tmp) (void)hipFree(d_tmp);
+    };
     hipError_t e;
-    if ((e = hipMalloc(&c->d_step_rec, rec.size() * sizeof(uint4))) != hipSuccess) return bail("hipMalloc step_rec", e);
-    if ((e = hipMalloc(&c->d_path_rec, prec.size() * sizeof(uint4))) != hipSuccess) return bail("hipMalloc path_rec", e);
-    if ((e = hipMalloc(&c->d_path_len, plen.size() * 8)) != hipSuccess) return bail("hipMalloc path_len", e);
-    if ((e = hipMemcpy(c->d_step_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy step_rec", e);
-    if ((e = hipMemcpy(c->d_path_rec, prec.data(), prec.size() * sizeof(uint4), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy path_rec", e);
-    if ((e = hipMemcpy(c->d_path_len, plen.data(), plen.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy path_len", e);
+#define GFS_TRY(what, expr) if ((e = (expr)) != hipSuccess) { free_tmp(); return bail(what, e); }
+    GFS_TRY("hipMalloc step_rec", hipMalloc(&c->d_step_rec, std::max<uint64_t>(S, 1) * sizeof(uint4)));
+    GFS_TRY("hipMalloc path_rec", hipMalloc(&c->d_path_rec, prec.size() * sizeof(uint4)));
+    GFS_TRY("hipMalloc path_len", hipMalloc(&c->d_path_len, std::max<uint64_t>(P, 1) * 8));
+    GFS_TRY("hipMalloc perm", hipMalloc(&c->d_perm, std::max<uint64_t>(N, 1) * 4));
+    GFS_TRY("hipMemcpy path_rec", hipMemcpy(c->d_path_rec, prec.data(), prec.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (N) GFS_TRY("hipMemcpy perm", hipMemcpy(c->d_perm, c->perm.data(), N * 4, hipMemcpyHostToDevice));
+    if (S) {
+        GFS_TRY("hipMalloc step_node", hipMalloc(&d_step_node, S * 4));
+        GFS_TRY("hipMalloc step_is_rev", hipMalloc(&d_rev, S));
+        GFS_TRY("hipMalloc node_len", hipMalloc(&d_node_len, std::max<uint64_t>(N, 1) * 4));
+        GFS_TRY("hipMalloc path_first", hipMalloc(&d_first, (P + 1) * 8));
+        GFS_TRY("hipMalloc scan", hipMalloc(&d_tmp, 2 * (S + 1) * 8));
+        GFS_TRY("hipMemcpy step_node", hipMemcpy(d_step_node, g->step_node, S * 4, hipMemcpyHostToDevice));
+        GFS_TRY("hipMemcpy step_is_rev", hipMemcpy(d_rev, g->step_is_rev, S, hipMemcpyHostToDevice));
+        if (N) GFS_TRY("hipMemcpy node_len", hipMemcpy(d_node_len, g->node_len, N * 4, hipMemcpyHostToDevice));
+        GFS_TRY("hipMemcpy path_first", hipMemcpy(d_first, g->path_first_step, (P + 1) * 8, hipMemcpyHostToDevice));
+        GFS_TRY("build_path_index", gfs::build_path_index_device(d_step_node, d_rev, d_node_len, c->d_perm, d_first, (uint32_t)P, S,
+                                                                  d_tmp, c->d_step_rec, c->d_path_len));
+    }
+#undef GFS_TRY
+    free_tmp();
     *out = c;
     return GFS_OK;
 }
@@ -468,6 +495,7 @@ void gfs_ctx_destroy(gfs_ctx *c) {
     if (c->d_step_rec) (void)hipFree(c->d_step_rec);
     if (c->d_path_rec) (void)hipFree(c->d_path_rec);
     if (c->d_path_len) (void)hipFree(c->d_path_len);
+    if (c->d_perm) (void)hipFree(c->d_perm);
     delete c;
 }
 
@@ -650,6 +678,26 @@ int gfs_ctx_trace(gfs_ctx *c, gfs_term *out, uint64_t n_terms, uint64_t *counts,
     return GFS_OK;
 }
 
+// K6 on the device: rank order of the context's current positions (1D) — sgd.rs:665-671.
+int gfs_ctx_sort_order(gfs_ctx *c, uint64_t *order, uint64_t n) {
+    if (!c || (!order && n)) return fail(GFS_E_ARG, "null argument");
+    if (!c->d_x || c->dims != 0) return fail(GFS_E_STATE, "needs a 1D context that has been set up");
+    if (n != c->n_nodes) return fail(GFS_E_ARG, "order length mismatch");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    void *d_tmp = nullptr;
+    HIPCHK(hipMalloc(&d_tmp, n * (2 * 8 + 2 * 4)));
+    uint32_t *d_order = nullptr;
+    hipError_t e = gfs::sort_order_device(c->d_x, c->d_perm, n, 1, d_tmp, &d_order);
+    if (e != hipSuccess) { (void)hipFree(d_tmp); return fail(GFS_E_HIP, std::string("sort_order_device: ") + hipGetErrorString(e)); }
+    std::vector<uint32_t> tmp(n);
+    e = hipMemcpy(tmp.data(), d_order, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(GFS_E_HIP, std::string("hipMemcpy order: ") + hipGetErrorString(e));
+    for (uint64_t k = 0; k < n; ++k) order[k] = tmp[k];
+    return GFS_OK;
+}
+
 // ---- multi-GPU replica merge helpers (device pointers, asynchronous on hip_stream) -----------------
 int gfs_merge_prepare(const double *x, const double *x_prev, float *buf2n, uint64_t n, void *hip_stream) {
     if (!x || !x_prev || !buf2n) return fail(GFS_E_ARG, "null argument");
@@ -668,7 +716,8 @@ int gfs_merge_apply(double *x, double *x_prev, const float *buf2n, uint64_t n, d
 
 // ---- one-shot entry points -------------------------------------------------------------------
 static int one_shot(const gfs_graph_view *g, const gfs_sgd_params *p, int dims, const gfs_launch_config *cfg,
-                    const double *etas, const double *zetas, int init_x, double *x, gfs_stats *stats) {
+                    const double *etas, const double *zetas, int init_x, double *x, gfs_stats *stats,
+                    uint64_t *order = nullptr) {
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (!g || !p) return fail(GFS_E_ARG, "null argument");
     if (g->n_nodes == 0) return GFS_NOTHING_TO_DO;                         // sgd.rs:242-244,780-782
@@ -694,6 +743,7 @@ static int one_shot(const gfs_graph_view *g, const gfs_sgd_params *p, int dims, 
     lap("run");
     if (!rc) rc = gfs_ctx_download_positions(c, x, gfs_ctx_positions_len(c));
     lap("download");
+    if (!rc && order) { rc = gfs_ctx_sort_order(c, order, g->n_nodes); lap("sort"); }
     if (!rc && stats) {
         rc = gfs_ctx_stats(c, stats);
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -706,6 +756,13 @@ static int one_shot(const gfs_graph_view *g, const gfs_sgd_params *p, int dims, 
 int gfs_path_linear_sgd(const gfs_graph_view *g, const gfs_sgd_params *p, const gfs_launch_config *cfg,
                         const double *etas, const double *zetas, int init_x, double *x_inout, gfs_stats *stats) {
     return one_shot(g, p, 0, cfg, etas, zetas, init_x, x_inout, stats);
+}
+
+int gfs_path_sgd_sort(const gfs_graph_view *g, const gfs_sgd_params *p, const gfs_launch_config *cfg,
+                      const double *etas, const double *zetas, int init_x, double *x_inout, uint64_t *order_out,
+                      gfs_stats *stats) {
+    if (!order_out) return fail(GFS_E_ARG, "order buffer is null");
+    return one_shot(g, p, 0, cfg, etas, zetas, init_x, x_inout, stats, order_out);
 }
 
 int gfs_path_linear_sgd_layout(const gfs_graph_view *g, const gfs_layout_params *p, const gfs_launch_config *cfg,

@@ -162,13 +162,22 @@ std::unordered_map<size_t, double> path_linear_sgd(const BidirectedGraph &g, con
 
 std::vector<Handle> path_sgd_sort(const BidirectedGraph &g, const PathSGDParams &p, const HipOptions &opt,
                                   gfs_stats *stats) {
-    // same result as sorting path_linear_sgd's map (sgd.rs:641-672), without materialising the map
-    FlatGraph f = g.flatten();
-    std::vector<double> x = path_linear_sgd_vec(g, f, p, opt, stats);
+    // same result as sorting path_linear_sgd's map (sgd.rs:641-672); the sort runs on the device
     std::vector<Handle> out;
-    if (x.empty()) return out;
+    if (g.node_count() == 0) return out;                             // sgd.rs:242-244
+    FlatGraph f = g.flatten();
+    gfs_graph_view v = f.view();
+    gfs_sgd_params cp = p.to_c();
+    std::vector<double> x(f.node_len.size());
     std::vector<uint64_t> order(x.size());
-    check(gfs_sort_order(x.data(), x.size(), order.data()));         // sgd.rs:665-666
+    gfs_stats st;
+    int rc = gfs_path_sgd_sort(&v, &cp, &opt.cfg, nullptr, nullptr, 1, x.data(), order.data(), &st);
+    check(rc);
+    if (stats) *stats = st;
+    if (rc == GFS_NOTHING_TO_DO) {
+        std::cerr << "[path_sgd] No paths with multiple steps found\n";   // sgd.rs:259
+        return out;
+    }
     out.reserve(order.size());
     for (uint64_t idx : order) out.push_back(Handle::forward(f.node_ids[idx]));   // idx -> handle, sgd.rs:649-662
     return out;

@@ -1,0 +1,112 @@
+// index_kernels.hip — the one-off passes either side of the SGD loop, on the device (rocPRIM for
+// the scan and the radix sort; the kernels around them are hand-written):
+//   K3  PathIndex::from_graph (src/sgd.rs:34-71): step positions = per-path exclusive prefix sum
+//       of node lengths over the steps, written straight into the 16-byte step records
+//   K6  path_sgd_sort's sort (src/sgd.rs:665-671): positions -> rank order
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <stdint.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace gfs {
+
+// ---- K3 ------------------------------------------------------------------------------------------
+// len[s] = sequence length of the step's node (0 for an absent node, sgd.rs:52-54); len[S] = 0
+__global__ void step_len_kernel(const uint32_t *step_node, const uint32_t *node_len, uint64_t *len, uint64_t n_steps) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= n_steps; s += stride) {
+        uint64_t l = 0;
+        if (s < n_steps) { const uint32_t n = step_node[s]; if (n != 0xFFFFFFFFu) l = node_len[n]; }
+        len[s] = l;
+    }
+}
+
+// rec[s] = { internal node slot | NO_NODE, path | rev<<31, pos lo, pos hi } with pos = scan[s] - scan[first(path)]
+__global__ void fill_records_kernel(const uint32_t *step_node, const uint8_t *step_is_rev, const uint32_t *perm,
+                                    const uint64_t *scan, const uint64_t *path_first, uint32_t n_paths,
+                                    uint4 *rec, uint64_t n_steps) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_steps; s += stride) {
+        // path of step s: last p with path_first[p] <= s (empty paths share a boundary: take the last)
+        uint32_t lo = 0, hi = n_paths;                 // invariant: path_first[lo] <= s < path_first[hi]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (path_first[mid] <= s) lo = mid; else hi = mid; }
+        const uint64_t pos = scan[s] - scan[path_first[lo]];
+        const uint32_t n = step_node[s];
+        uint4 r;
+        r.x = n == 0xFFFFFFFFu ? 0xFFFFFFFFu : perm[n];
+        r.y = lo | ((uint32_t)(step_is_rev[s] & 1) << 31);
+        r.z = (uint32_t)pos; r.w = (uint32_t)(pos >> 32);
+        rec[s] = r;
+    }
+}
+
+__global__ void path_len_kernel(const uint64_t *scan, const uint64_t *path_first, uint64_t *path_len, uint32_t n_paths) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_paths) path_len[p] = scan[path_first[p + 1]] - scan[path_first[p]];
+}
+
+// All pointers are device pointers; tmp holds 2*(n_steps+1) u64 (len, scan).  Synchronous.
+hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
+                                   const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
+                                   uint64_t n_steps, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len) {
+    uint64_t *d_len = d_tmp, *d_scan = d_tmp + (n_steps + 1);
+    const unsigned blocks = 2048;
+    hipLaunchKernelGGL(step_len_kernel, dim3(blocks), dim3(256), 0, 0, d_step_node, d_node_len, d_len, n_steps);
+    size_t tmp_bytes = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_len, d_scan, (uint64_t)0, (size_t)(n_steps + 1),
+                                           rocprim::plus<uint64_t>(), 0);
+    if (e != hipSuccess) return e;
+    void *d_scan_tmp = nullptr;
+    if ((e = hipMalloc(&d_scan_tmp, tmp_bytes ? tmp_bytes : 8)) != hipSuccess) return e;
+    e = rocprim::exclusive_scan(d_scan_tmp, tmp_bytes, d_len, d_scan, (uint64_t)0, (size_t)(n_steps + 1),
+                                rocprim::plus<uint64_t>(), 0);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fill_records_kernel, dim3(blocks), dim3(256), 0, 0, d_step_node, d_step_is_rev, d_perm, d_scan,
+                           d_path_first, n_paths, d_rec, n_steps);
+        hipLaunchKernelGGL(path_len_kernel, dim3((n_paths + 255) / 256), dim3(256), 0, 0, d_scan, d_path_first, d_path_len, n_paths);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipDeviceSynchronize();
+    (void)hipFree(d_scan_tmp);
+    return e != hipSuccess ? e : e2;
+}
+
+// ---- K6 ------------------------------------------------------------------------------------------
+// Order-preserving u64 image of an f64: -0.0 is folded onto +0.0 (partial_cmp calls them equal, so the
+// tie must be broken by index, sgd.rs:666); NaNs (never produced by a finite run) sort after all numbers.
+__device__ __forceinline__ uint64_t orderable(double v) {
+    if (v != v) return 0xFFFFFFFFFFFFFFFFull;
+    if (v == 0.0) v = 0.0;
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+// keys in DENSE-index order (the device vector is in layout order), so that the stable sort breaks ties by dense index
+__global__ void sort_keys_kernel(const double *x_layout, const uint32_t *perm, uint64_t *keys, uint32_t *vals, uint64_t n,
+                                 uint64_t stride_doubles) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        keys[k] = orderable(x_layout[(uint64_t)perm[k] * stride_doubles]);
+        vals[k] = (uint32_t)k;
+    }
+}
+
+// d_order_out[r] = dense index of the node of rank r.  d_tmp: 2*n u64 keys + 2*n u32 values.  Synchronous.
+hipError_t sort_order_device(const double *d_x_layout, const uint32_t *d_perm, uint64_t n, uint64_t stride_doubles,
+                             void *d_tmp, uint32_t **d_order_out) {
+    uint64_t *k_in = reinterpret_cast<uint64_t *>(d_tmp), *k_out = k_in + n;
+    uint32_t *v_in = reinterpret_cast<uint32_t *>(k_out + n), *v_out = v_in + n;
+    hipLaunchKernelGGL(sort_keys_kernel, dim3(1024), dim3(256), 0, 0, d_x_layout, d_perm, k_in, v_in, n, stride_doubles);
+    size_t tmp_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, 64, 0);
+    if (e != hipSuccess) return e;
+    void *d_sort_tmp = nullptr;
+    if ((e = hipMalloc(&d_sort_tmp, tmp_bytes ? tmp_bytes : 8)) != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(d_sort_tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, 64, 0);   // stable
+    hipError_t e2 = hipDeviceSynchronize();
+    (void)hipFree(d_sort_tmp);
+    *d_order_out = v_out;
+    return e != hipSuccess ? e : e2;
+}
+
+}  // namespace gfs

@@ -62,12 +62,12 @@ TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)
 EXPORTS = [
     "gfs_version", "gfs_last_error", "gfs_device_count", "gfs_warmup", "gfs_fast_precise_pow", "gfs_sgd_schedule",
     "gfs_zeta_table_len", "gfs_zeta_table", "gfs_init_positions", "gfs_init_layout_dim0",
-    "gfs_sort_order", "gfs_path_linear_sgd", "gfs_path_linear_sgd_layout", "gfs_ctx_create",
+    "gfs_sort_order", "gfs_path_linear_sgd", "gfs_path_sgd_sort", "gfs_path_linear_sgd_layout", "gfs_ctx_create",
     "gfs_ctx_create_with_layout", "gfs_ctx_node_layout",
     "gfs_ctx_destroy", "gfs_ctx_setup_1d", "gfs_ctx_setup_nd", "gfs_ctx_positions_len",
     "gfs_ctx_upload_positions", "gfs_ctx_download_positions", "gfs_ctx_positions_device",
     "gfs_ctx_bind_positions", "gfs_ctx_reset_streams", "gfs_ctx_run_iteration", "gfs_ctx_run",
-    "gfs_ctx_synchronize", "gfs_ctx_stats", "gfs_ctx_trace", "gfs_merge_prepare", "gfs_merge_apply",
+    "gfs_ctx_synchronize", "gfs_ctx_stats", "gfs_ctx_sort_order", "gfs_ctx_trace", "gfs_merge_prepare", "gfs_merge_apply",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def lib():
         L.gfs_ctx_upload_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gfs_ctx_download_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gfs_ctx_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_ctx_sort_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gfs_ctx_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.gfs_ctx_node_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gfs_ctx_setup_1d.argtypes = [C.c_void_p] + [C.c_void_p] * 4
@@ -289,6 +290,12 @@ class Context:
         check(lib().gfs_ctx_stats(self._h, C.byref(st)))
         return st
 
+    def sort_order(self):
+        """Rank order of the current 1D positions, sorted on the device."""
+        order = np.zeros(self.graph.n_nodes, dtype=np.uint64)
+        check(lib().gfs_ctx_sort_order(self._h, _ptr(order), C.c_uint64(order.shape[0])))
+        return order
+
     def trace(self):
         st = self.stats()
         k = int(self.cfg.trace_per_stream)
@@ -312,6 +319,21 @@ def path_linear_sgd_raw(g, p, x=None, cfg=None, etas=None, zetas=None):
     rc = check(lib().gfs_path_linear_sgd(C.byref(v), C.byref(sp), C.byref(cfg) if cfg is not None else None,
                                          _ptr(etas), _ptr(zetas), C.c_int(init), _ptr(x), C.byref(st)))
     return rc, x, st
+
+
+def path_sgd_sort_raw(g, p, x=None, cfg=None, etas=None, zetas=None):
+    """gfs_path_sgd_sort.  Returns (rc, x, order, stats)."""
+    v, keep = make_view(g)
+    sp = make_sgd_params(p)
+    init = 1 if x is None else 0
+    if x is None:
+        x = np.zeros(g.n_nodes, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    order = np.zeros(g.n_nodes, dtype=np.uint64)
+    st = Stats()
+    rc = check(lib().gfs_path_sgd_sort(C.byref(v), C.byref(sp), C.byref(cfg) if cfg is not None else None,
+                                       _ptr(etas), _ptr(zetas), C.c_int(init), _ptr(x), _ptr(order), C.byref(st)))
+    return rc, x, order, st
 
 
 def path_linear_sgd_layout_raw(g, p, coords, cfg=None, etas=None, zetas=None):

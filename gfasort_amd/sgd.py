@@ -31,10 +31,12 @@ def path_linear_sgd(graph: FlatGraph, params: PathSGDParams, cfg=None,
 def path_sgd_sort(graph: FlatGraph, params: PathSGDParams, cfg=None) -> np.ndarray:
     """sgd.rs:641-672: dense node indices in ascending position order.  (The reference breaks
     ties by HashMap iteration order, i.e. randomly; here ties keep node_order.)"""
-    x = path_linear_sgd(graph, params, cfg)
-    if x.shape[0] == 0:
+    if graph.n_nodes == 0:
         return np.zeros(0, dtype=np.uint64)
-    return hip.sort_order(x)
+    rc, x, order, st = hip.path_sgd_sort_raw(graph, params, cfg=cfg)       # SGD + device radix sort
+    if rc == hip.NOTHING_TO_DO:
+        return np.zeros(0, dtype=np.uint64)
+    return order
 
 
 def sgd_sort_only(graph: FlatGraph, params: PathSGDParams, verbose: int = 0, cfg=None) -> np.ndarray:

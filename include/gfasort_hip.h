@@ -153,6 +153,11 @@ int      gfs_sort_order(const double *x, uint64_t n, uint64_t *order);
 int gfs_path_linear_sgd(const gfs_graph_view *g, const gfs_sgd_params *p,
                         const gfs_launch_config *cfg, const double *etas, const double *zetas,
                         int init_x, double *x_inout, gfs_stats *stats);
+/* replaces path_sgd_sort (src/sgd.rs:641): the same run, plus order_out[r] = dense index of the node
+ * of rank r (ascending position, ties by dense index; sorted on the device).  x_inout as above.   */
+int gfs_path_sgd_sort(const gfs_graph_view *g, const gfs_sgd_params *p,
+                      const gfs_launch_config *cfg, const double *etas, const double *zetas,
+                      int init_x, double *x_inout, uint64_t *order_out, gfs_stats *stats);
 /* replaces path_linear_sgd_layout (src/sgd.rs:773).  coords_inout[n_nodes*2*D] in the order of
  * Layout.coords: coords[node*2*D + end*D + dim] (src/layout.rs:14,73-78).                   */
 int gfs_path_linear_sgd_layout(const gfs_graph_view *g, const gfs_layout_params *p,
@@ -186,6 +191,8 @@ int   gfs_ctx_run_iteration(gfs_ctx *ctx, uint64_t k, void *hip_stream);
 int   gfs_ctx_run(gfs_ctx *ctx, void *hip_stream);               /* k = 0..=iter_max, then sync */
 int   gfs_ctx_synchronize(gfs_ctx *ctx, void *hip_stream);
 int   gfs_ctx_stats(gfs_ctx *ctx, gfs_stats *out);               /* synchronises                */
+/* rank order of the context's current 1D positions, sorted on the device (rocPRIM radix sort)   */
+int   gfs_ctx_sort_order(gfs_ctx *ctx, uint64_t *order, uint64_t n_nodes);
 int   gfs_ctx_trace(gfs_ctx *ctx, gfs_term *out, uint64_t n_terms, uint64_t *counts, uint64_t n_streams);
 
 /* ---- multi-GPU replica merge (device pointers; no reference equivalent) ----

@@ -566,3 +566,26 @@ def test_many_launches_recycle_event_pool():
     st = ctx.stats()
     assert st.iterations == 5050 and st.term_updates == 5050 * p.min_term_updates and st.kernel_ms > 0
     ctx.close()
+
+
+def test_device_sort_and_device_path_index():
+    """K6 on the device equals the host sort (ties by dense index, -0.0 == +0.0); K3 on the device feeds the
+    bit-exact replay tests above, here checked once more through gfs_path_sgd_sort."""
+    g = load("DRB1-3123.gfa")
+    p = _ygs(g, 10)
+    rc, x, order, st = hip.path_sgd_sort_raw(g, p, cfg=hip.make_config(n_streams=1))
+    assert rc == 0 and np.array_equal(order, hip.sort_order(x))
+    og = oracle_graph(g)
+    x_ref = O.init_positions(og)
+    O.sgd_1d(og, oracle_params(p), x_ref, n_streams=1)
+    assert np.array_equal(x.view(np.uint64), x_ref.view(np.uint64))
+    assert np.array_equal(order.astype(np.int64), np.argsort(x_ref, kind="stable"))
+    # ties and signed zeros through the context API
+    g2 = G.synth_chain(1000, 2)
+    ctx = hip.Context(g2)
+    ctx.setup_1d(_ygs(g2, 1), hip.make_config(n_streams=64))
+    xs = np.round(np.random.default_rng(0).normal(size=1000) * 3)          # many ties
+    xs[xs == 0] = np.where(np.arange((xs == 0).sum()) % 2 == 0, 0.0, -0.0)
+    ctx.upload(xs)
+    assert np.array_equal(ctx.sort_order().astype(np.int64), np.argsort(xs + 0.0, kind="stable"))
+    ctx.close()
