@@ -237,6 +237,79 @@ static int seed_streams(gfs_ctx *c) {
     return GFS_OK;
 }
 
+// The zeta table of sgd.rs:311-331 on the device.  Only indices reachable from
+// jump <= min(space, max_path_steps-1) are ever read (sgd.rs:462-469); when the table is computed here
+// the running sum — which is order-dependent and must be accumulated exactly as the reference does —
+// stops at the largest i that feeds a reachable entry (space is the longest path in bp: 1.3e6 for C3,
+// of which 1.6e5 matter).
+static int upload_zeta_table(gfs_ctx *c, const gfs_sgd_params *p, const double *zetas) {
+    c->zlen_full = gfs_zeta_table_len(p);
+    if (c->zlen_full > 0xFFFFFFFFull) return fail(GFS_E_UNSUPPORTED, "zeta table too long");
+    const uint64_t maxjump = std::min<uint64_t>(p->space, c->max_path_steps ? c->max_path_steps - 1 : 0);
+    const uint64_t last_idx = maxjump > p->space_max
+                                  ? p->space_max + (maxjump - p->space_max) / p->space_quantization_step + 1
+                                  : maxjump;
+    c->zlen_staged = std::min<uint64_t>(last_idx + 1, c->zlen_full);
+    std::vector<double> ztab;
+    if (!zetas) {
+        const uint64_t m = c->zlen_staged - 1;                      // last staged index
+        const uint64_t need_i = m <= p->space_max ? m : p->space_max + (m - p->space_max - 1) * p->space_quantization_step;
+        gfs_sgd_params q = *p;
+        q.space = std::min<uint64_t>(p->space, std::max<uint64_t>(need_i, 1));
+        std::vector<double> part(gfs_zeta_table_len(&q));
+        gfs_zeta_table(&q, part.data());
+        ztab.assign(c->zlen_full, 0.0);
+        std::copy(part.begin(), part.begin() + std::min<size_t>(part.size(), ztab.size()), ztab.begin());
+        zetas = ztab.data();
+    }
+    HIPCHK(hipMalloc(&c->d_zetas, c->zlen_full * 8));
+    HIPCHK(hipMemcpy(c->d_zetas, zetas, c->zlen_full * 8, hipMemcpyHostToDevice));
+    return GFS_OK;
+}
+
+// Streams per launch when the caller leaves it to the library.
+static uint64_t auto_stream_count(const gfs_ctx *c) {
+    // 512 lanes per CU (2 waves per SIMD) measured best on MI355X for the team kernel and within
+    // 5 % of best for reference streams (profiles/r01/sweep_streams*.log): more resident waves only
+    // lengthen the queues in front of the memory-side atomic units.
+    const uint64_t chip = (uint64_t)c->cu_count * 512;
+    // keep >= 8 updates per stream per batch on small graphs
+    const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
+    // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight
+    // term corrects its two nodes from positions read before the others landed, so with ~2 concurrent
+    // terms per node and mu clamped at 1 the corrections overshoot — a 6000-node graph of short paths
+    // diverged (stress 1e8) under 6784 streams and converges under 1024
+    // (profiles/r01/stream_cap_probe.log).  An explicit n_streams overrides this.
+    const uint64_t by_nodes = (c->n_nodes / 4) / 64 * 64;
+    return std::max<uint64_t>(64, std::min(chip, std::min(by_work, by_nodes)));
+}
+
+// Sampling bundle: flags bits 16..23: 0 = auto, 1 = reference streams, 4..64 explicit (sgd_device.h).
+static int choose_bundle(gfs_ctx *c, int dims) {
+    const uint64_t T = c->n_streams;
+    uint32_t b = (c->cfg.flags >> 16) & 0xFFu;
+    if (b > 1 && (T % 64 != 0 || (b != 4 && b != 8 && b != 16 && b != 32 && b != 64)))
+        return fail(GFS_E_ARG, "bundled sampling needs n_streams % 64 == 0 and a bundle of 4, 8, 16, 32 or 64");
+    if (b > 1 && dims != 0 && (dims > 3 || b == 4))
+        return fail(GFS_E_UNSUPPORTED, "bundled layout kernels exist for 1..3 dimensions and bundles of 8..64");
+    if (b == 0) {
+        // auto: the widest bundle that still leaves >= 65536 independent leader draws per iteration and
+        // has >= 95 % of the steps in paths of at least 4*B steps.  Small graphs run reference streams.
+        b = 1;
+        if (T % 64 == 0 && dims <= 3) {
+            for (uint32_t cand : {64u, 32u, 16u, 8u, 4u}) {
+                if (cand == 4u && dims != 0) continue;
+                if (c->quota_total / cand < 65536) continue;
+                uint64_t long_steps = 0;
+                for (uint32_t cnt : c->path_counts) if (cnt >= 4 * cand) long_steps += cnt;
+                if ((double)long_steps >= 0.95 * (double)c->n_steps) { b = cand; break; }
+            }
+        }
+    }
+    c->bundle = b;
+    return GFS_OK;
+}
+
 static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs_launch_config *cfg,
                         const double *etas, const double *zetas) {
     if (!c) return fail(GFS_E_ARG, "ctx is null");
@@ -254,41 +327,8 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     c->etas.resize(p->iter_max + 1);
     if (etas) std::copy(etas, etas + p->iter_max + 1, c->etas.begin());
     else gfs_sgd_schedule(p, c->etas.data());
-    c->zlen_full = gfs_zeta_table_len(p);
-    if (c->zlen_full > 0xFFFFFFFFull) return fail(GFS_E_UNSUPPORTED, "zeta table too long");
-    // Only indices reachable from jump <= min(space, max_path_steps-1) are ever read (sgd.rs:462-469)
-    {
-        uint64_t maxjump = std::min<uint64_t>(p->space, c->max_path_steps ? c->max_path_steps - 1 : 0);
-        uint64_t idx = maxjump > p->space_max
-                           ? p->space_max + (maxjump - p->space_max) / p->space_quantization_step + 1
-                           : maxjump;
-        c->zlen_staged = std::min<uint64_t>(idx + 1, c->zlen_full);
-    }
-    {
-        std::vector<double> ztab;
-        const double *zsrc = zetas;
-        if (!zsrc) {
-            // the running sum is order-dependent: compute the prefix that is reachable, exactly as
-            // the reference accumulates it (entries beyond zlen_staged are never read)
-            gfs_sgd_params q = *p;
-            ztab.resize(c->zlen_full);
-            // cap the summation at the largest i that feeds a staged entry
-            uint64_t need_i = c->zlen_staged <= p->space_max + 1
-                                  ? c->zlen_staged - 1
-                                  : p->space_max + (c->zlen_staged - 1 - p->space_max - 1) * p->space_quantization_step;
-            q.space = std::min<uint64_t>(p->space, std::max<uint64_t>(need_i, 1));
-            std::vector<double> part(gfs_zeta_table_len(&q));
-            gfs_zeta_table(&q, part.data());
-            std::fill(ztab.begin(), ztab.end(), 0.0);
-            std::copy(part.begin(), part.begin() + std::min<size_t>(part.size(), ztab.size()), ztab.begin());
-            zsrc = ztab.data();
-            HIPCHK(hipMalloc(&c->d_zetas, c->zlen_full * 8));
-            HIPCHK(hipMemcpy(c->d_zetas, zsrc, c->zlen_full * 8, hipMemcpyHostToDevice));
-        } else {
-            HIPCHK(hipMalloc(&c->d_zetas, c->zlen_full * 8));
-            HIPCHK(hipMemcpy(c->d_zetas, zsrc, c->zlen_full * 8, hipMemcpyHostToDevice));
-        }
-    }
+    rc = upload_zeta_table(c, p, zetas);
+    if (rc) return rc;
 
     // positions
     c->x_len = dims ? c->n_nodes * 2 * (uint64_t)dims : c->n_nodes;
@@ -300,50 +340,14 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     c->quota_total = c->cfg.term_updates_per_iteration ? c->cfg.term_updates_per_iteration : p->min_term_updates;
     c->block = c->cfg.block_size ? c->cfg.block_size : 256;
     if (c->block % 64 || c->block > 1024) return fail(GFS_E_ARG, "block_size must be a multiple of 64, <= 1024");
-    uint64_t T = c->cfg.n_streams;
-    if (T == 0) {
-        // 512 lanes per CU (2 waves per SIMD) measured best on MI355X for the team kernel and
-        // within 5 % of best for reference streams (profiles/r01/sweep_streams*.log): more resident
-        // waves only lengthen the queues in front of the memory-side atomic units.  Keep >= 8
-        // updates per stream per batch on small graphs.
-        uint64_t chip = (uint64_t)c->cu_count * 512;
-        uint64_t want = (c->quota_total + 7) / 8;
-        // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every
-        // in-flight term corrects its two nodes from positions read before the others landed, so
-        // with ~2 concurrent terms per node and mu clamped at 1 the corrections overshoot — a
-        // 6000-node graph of short paths diverged (stress 1e8) under 6784 streams and converges
-        // under 1024 (profiles/r01/stream_cap_probe.log).  Explicit n_streams overrides this.
-        uint64_t by_nodes = std::max<uint64_t>(64, (c->n_nodes / 4) / 64 * 64);
-        T = std::max<uint64_t>(64, std::min<uint64_t>(std::min(chip, by_nodes), (want + 63) / 64 * 64));
-    }
+    const uint64_t T = c->cfg.n_streams ? c->cfg.n_streams : auto_stream_count(c);
     if (T > 0x7FFFFFFFull) return fail(GFS_E_ARG, "n_streams too large");
     c->n_streams = T;
     if (c->quota_total / T + 1 > 0xFFFFFFFFull) return fail(GFS_E_UNSUPPORTED, "per-stream quota exceeds 2^32");
     if (c->cfg.attempt_factor == 0) c->cfg.attempt_factor = 64;
     if (c->cfg.attempt_factor > 0xFFFFFFFFull) return fail(GFS_E_ARG, "attempt_factor too large");
-    {   // sampling bundle: 0 = auto, 1 = reference streams, 4..64 explicit (sgd_device.h)
-        uint32_t b = (c->cfg.flags >> 16) & 0xFFu;
-        if (b > 1 && (T % 64 != 0 || (b != 4 && b != 8 && b != 16 && b != 32 && b != 64)))
-            return fail(GFS_E_ARG, "bundled sampling needs n_streams % 64 == 0 and a bundle of 4, 8, 16, 32 or 64");
-        if (b > 1 && dims != 0 && (dims > 3 || b == 4))
-            return fail(GFS_E_UNSUPPORTED, "bundled layout kernels exist for 1..3 dimensions and bundles of 8..64");
-        if (b == 0) {
-            // auto: the widest bundle that still leaves >= 65536 independent bundle draws per
-            // iteration and has >= 95 % of the steps in paths of at least 4*B steps.  Small graphs
-            // therefore run reference streams.
-            b = 1;
-            if (T % 64 == 0 && dims <= 3) {
-                for (uint32_t cand : {64u, 32u, 16u, 8u, 4u}) {
-                    if (cand == 4u && dims != 0) continue;
-                    if (c->quota_total / cand < 65536) continue;
-                    uint64_t long_steps = 0;
-                    for (uint32_t cnt : c->path_counts) if (cnt >= 4 * cand) long_steps += cnt;
-                    if ((double)long_steps >= 0.95 * (double)c->n_steps) { b = cand; break; }
-                }
-            }
-        }
-        c->bundle = b;
-    }
+    rc = choose_bundle(c, dims);
+    if (rc) return rc;
     c->atomic_loads = !(c->cfg.flags & GFS_F_PLAIN_LOADS);
     size_t lds = (size_t)c->n_paths * sizeof(uint4) + (size_t)c->zlen_staged * 8;
     c->lds_tables = !(c->cfg.flags & GFS_F_NO_LDS_TABLES) && lds <= 48 * 1024;
