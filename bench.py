@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--bundle", type=int, default=0, help="sampling bundle: 0 = library auto policy, 1 = reference streams")
+    ap.add_argument("--merge-every", type=int, default=4,
+                    help="N>1: iterations between replica merges (all-reduce); quality at 8 ranks measured in "
+                         "profiles/r01/virtual_cluster.log")
     ap.add_argument("--block", type=int, default=0)
     args = ap.parse_args()
 
@@ -176,7 +179,8 @@ def main():
     runner = ShardedSGD(g, p, rank, world,
                         hip_engine_factory(device_index=local_rank, flags=args.flags | hip.F_BUNDLE(args.bundle),
                                            block_size=args.block),
-                        dims=0, streams_per_rank=args.streams, dist=dist if world > 1 else None)
+                        dims=0, streams_per_rank=args.streams, dist=dist if world > 1 else None,
+                        merge_every=args.merge_every)
     x0 = hip.init_positions(g)
     n_sched = int(p.iter_max) + 1
 
@@ -239,7 +243,8 @@ def main():
                                    "-p Y --iter-max 200, 1e7 term updates per step",
                        "term_updates_per_step": M, "n_streams_per_gpu": int(st1.n_streams),
                        "sampling_bundle": int(st1.bundle),
-                       "parallelism": f"paths sharded x{world}, positions replicated, delta all-reduce/iter"
+                       "parallelism": f"paths sharded x{world}, positions replicated, f32 [delta,touched] all-reduce "
+                                      f"every {args.merge_every} iterations"
                        if world > 1 else "single GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

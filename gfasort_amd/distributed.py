@@ -25,6 +25,27 @@ import numpy as np
 from .graph import FlatGraph
 
 
+def shard_paths_contiguous(step_counts: np.ndarray, world: int) -> List[List[int]]:
+    """Consecutive blocks of paths with (nearly) equal step totals: rank r gets the paths whose
+    cumulative-step midpoint falls into the r-th 1/world of the total."""
+    counts = np.asarray(step_counts, dtype=np.float64)
+    total = float(counts.sum())
+    shards: List[List[int]] = [[] for _ in range(world)]
+    if total <= 0:
+        return shards
+    mid = np.cumsum(counts) - counts / 2.0
+    owner = np.minimum((mid * world / total).astype(np.int64), world - 1)
+    for p, r in enumerate(owner.tolist()):
+        shards[r].append(p)
+    return shards
+
+
+def shard_imbalance(step_counts: np.ndarray, shards: List[List[int]]) -> float:
+    loads = [float(sum(int(step_counts[p]) for p in s)) for s in shards]
+    mean = sum(loads) / max(len(loads), 1)
+    return (max(loads) / mean - 1.0) if mean > 0 else 0.0
+
+
 def shard_paths(step_counts: np.ndarray, world: int) -> List[List[int]]:
     """Longest-processing-time-first bin packing of paths onto ranks (deterministic)."""
     order = sorted(range(len(step_counts)), key=lambda p: (-int(step_counts[p]), p))
@@ -95,11 +116,19 @@ class ShardedSGD:
     HipEngine below; tests inject a CPU engine to exercise this logic under gloo."""
 
     def __init__(self, graph: FlatGraph, params, rank: int, world: int, engine_factory: Callable,
-                 dims: int = 0, streams_per_rank: int = 0, merge: str = "touch", dist=None):
+                 dims: int = 0, streams_per_rank: int = 0, merge: str = "touch", dist=None,
+                 merge_every: int = 1, sharding: str = "auto"):
         self.rank, self.world, self.merge = rank, world, merge
         self.dist = dist
+        self.merge_every = max(1, int(merge_every))
         counts = graph.path_step_counts()
-        self.shards = shard_paths(counts, world)
+        # consecutive blocks keep a rank's paths (and so the nodes it moves) together when the paths
+        # of the input are ordered along the graph; fall back to LPT packing when that is unbalanced
+        contiguous = shard_paths_contiguous(counts, world)
+        if sharding == "contiguous" or (sharding == "auto" and shard_imbalance(counts, contiguous) <= 0.10):
+            self.shards = contiguous
+        else:
+            self.shards = shard_paths(counts, world)
         steps = [int(sum(int(counts[p]) for p in s)) for s in self.shards]
         self.quotas = shard_quotas(int(params.min_term_updates), steps)
         local = graph if world == 1 else subgraph(graph, self.shards[rank])
@@ -123,7 +152,8 @@ class ShardedSGD:
 
     def run_iteration(self, k: int):
         self.engine.run_iteration(k)
-        if self.world > 1:
+        last = k == int(self.params.iter_max)
+        if self.world > 1 and ((k + 1) % self.merge_every == 0 or last):
             torch = self._torch
             x = self.engine.positions
             n = x.shape[0]
