@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--bundle", type=int, default=0, help="sampling bundle: 0 = library auto policy, 1 = reference streams")
-    ap.add_argument("--merge-every", type=int, default=4,
+    ap.add_argument("--merge-every", type=int, default=8,
                     help="N>1: iterations between replica merges (all-reduce); quality at 8 ranks measured in "
                          "profiles/r01/virtual_cluster.log")
     ap.add_argument("--block", type=int, default=0)
