@@ -391,7 +391,7 @@ int gfs_ctx_create(const gfs_graph_view *g, int device, gfs_ctx **out) {
 int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32_t *node_perm, gfs_ctx **out) {
     if (!g || !out) return fail(GFS_E_ARG, "null argument");
     *out = nullptr;
-    if (g->n_steps > 0xFFFFFFFEull) return fail(GFS_E_UNSUPPORTED, "more than 2^32-2 path steps");
+    if (g->n_steps > (1ull << 40)) return fail(GFS_E_UNSUPPORTED, "more than 2^40 path steps");
     if (g->n_nodes > 0x7FFFFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^31-1 nodes");
     if (g->n_paths > 0x7FFFFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^31-1 paths");
     if (g->n_steps && (!g->step_node || !g->step_is_rev)) return fail(GFS_E_ARG, "null step arrays");
@@ -444,8 +444,9 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     for (uint64_t p = 0; p < g->n_paths; ++p) {
         uint64_t b = g->path_first_step[p], e = g->path_first_step[p + 1];
         uint32_t cnt = (uint32_t)(e - b);
+        if (e - b > 0xFFFFFFFFull) { delete c; return fail(GFS_E_UNSUPPORTED, "a path with more than 2^32-1 steps"); }
         prec[p].x = (uint32_t)b; prec[p].y = cnt;
-        prec[p].z = cnt ? (uint32_t)(0u - cnt) % cnt : 0u; prec[p].w = 0;
+        prec[p].z = cnt ? (uint32_t)(0u - cnt) % cnt : 0u; prec[p].w = (uint32_t)(b >> 32);
         c->path_counts.push_back(cnt);
         if (cnt > 1) c->valid_paths = true;                               // sgd.rs:250-256
         c->max_path_steps = std::max(c->max_path_steps, cnt);
@@ -574,8 +575,10 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     a.step_rec = c->d_step_rec; a.path_rec = c->d_path_rec; a.path_len = c->d_path_len;
     a.zetas = c->d_zetas; a.x = c->d_x; a.rng = c->d_rng; a.counters = c->d_counters;
     a.trace = c->d_trace; a.trace_cnt = c->d_trace_cnt;
-    a.n_steps = (uint32_t)c->n_steps;
-    a.steps_thresh = (uint32_t)(0u - a.n_steps) % a.n_steps;
+    a.n_steps = c->n_steps;
+    const bool wide = c->n_steps > 0xFFFFFFFFull || (c->cfg.flags & GFS_F_DBG_WIDE_INDEX);
+    a.steps_thresh = wide ? (0ull - c->n_steps) % c->n_steps
+                          : (uint64_t)((uint32_t)(0u - (uint32_t)c->n_steps) % (uint32_t)c->n_steps);
     a.n_paths = (uint32_t)c->n_paths;
     a.zlen_full = (uint32_t)c->zlen_full; a.zlen_staged = (uint32_t)c->zlen_staged;
     a.n_streams = (uint32_t)c->n_streams;
@@ -586,7 +589,7 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     a.space = (uint32_t)std::min<uint64_t>(c->params.space, 0xFFFFFFFFull);
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
-    a.dbg = (c->cfg.flags >> 8) & 0x7Fu;
+    a.dbg = (c->cfg.flags >> 8) & 0x7Fu;             // bit 0x40 = GFS_F_DBG_WIDE_INDEX >> 8
     if (4 * c->n_streams <= c->n_nodes) a.dbg |= 0x80u;      // team kernel: defer atomics by one trip
     a.bundle = c->bundle;
     iter_consts(c, k, a.it);

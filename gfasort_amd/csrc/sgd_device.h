@@ -61,6 +61,13 @@ struct Rng {
             if ((uint32_t)m >= thresh) return (uint32_t)(m >> 32);
         }
     }
+    // ... and for n > u32::MAX: u64 draws, 128-bit widening multiply, thresh = (2^64 - n) mod n
+    __device__ __forceinline__ uint64_t uniform64(uint64_t n, uint64_t thresh) {
+        for (;;) {
+            const uint64_t r = next();
+            if (r * n >= thresh) return __umul64hi(r, n);
+        }
+    }
 };
 
 // ---- launch-uniform constants of one SGD batch (host-computed, bit-exact) ----------------
@@ -77,7 +84,7 @@ struct IterConsts {
 
 // device mirror of PathIndex (sgd.rs:14-31), flattened:
 //   step_rec[s]  = { node dense idx | NO_NODE, path id | rev<<31, pos lo, pos hi }  (16 B)
-//   path_rec[p]  = { first_step, step_count, (2^32-count) mod count, 0 }            (16 B)
+//   path_rec[p]  = { first_step lo, step_count, (2^32-count) mod count, first_step hi } (16 B)
 struct KArgs {
     const uint4    *step_rec;
     const uint4    *path_rec;
@@ -88,7 +95,7 @@ struct KArgs {
     unsigned long long *counters;  // [0] successful updates, [1] attempts
     void           *trace;         // gfs_term[n_streams*trace_per_stream] or null
     uint32_t       *trace_cnt;     // [n_streams]
-    uint32_t n_steps, steps_thresh;
+    uint64_t n_steps, steps_thresh;   // thresh = (2^w - n) mod n, w = 32 if n_steps <= u32::MAX else 64
     uint32_t n_paths, zlen_full;   // zlen_full: true table length (index clamp, sgd.rs:469)
     uint32_t zlen_staged;          // entries copied to LDS (>= every reachable index)
     uint32_t n_streams;
@@ -99,6 +106,14 @@ struct KArgs {
     uint32_t bundle, _pad2;        // lanes per sampling bundle (1 = reference streams)
     IterConsts it;
 };
+
+// step_idx ~ U[0, total_steps) (sgd.rs:444): rand's usize sampler draws u32 while the range fits
+// u32 and u64 beyond — graphs past 2^32 steps fit a 288 GB MI355X (16 B per step record).
+__device__ __forceinline__ uint64_t sample_step(const KArgs &a, Rng &rng) {
+    if (a.n_steps <= 0xFFFFFFFFull && !(a.dbg & 0x40u)) return rng.uniform32((uint32_t)a.n_steps, (uint32_t)a.steps_thresh);
+    return rng.uniform64(a.n_steps, a.steps_thresh);
+}
+__device__ __forceinline__ uint64_t path_first(const uint4 &pr) { return ((uint64_t)pr.w << 32) | pr.x; }
 
 // zeta index rule (sgd.rs:463-469)
 __device__ __forceinline__ uint32_t space_index(const KArgs &a, uint32_t jump) {
@@ -126,15 +141,15 @@ __device__ __forceinline__ uint32_t dirty_zipf(const IterConsts &c, uint32_t jum
 // One trip of the pair sampler, sgd.rs:444-499 == :990-1037.  Returns false on `continue`.
 template <bool LDS_TABLES>
 __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
-                                            Rng &rng, uint4 &ra, uint4 &rb, uint32_t &sa, uint32_t &sb,
+                                            Rng &rng, uint4 &ra, uint4 &rb, uint64_t &sa, uint64_t &sb,
                                             uint32_t &cnt_out, uint32_t &path_out) {
-    uint32_t step_idx = rng.uniform32(a.n_steps, a.steps_thresh);                      // :444
+    const uint64_t step_idx = sample_step(a, rng);                                     // :444
     ra = a.step_rec[step_idx];
     uint32_t path = ra.y & 0x7FFFFFFFu;                                                // :445
     uint4 pr = path_tab[path];
-    uint32_t first = pr.x, cnt = pr.y;                                                 // :446
+    const uint64_t first = path_first(pr); const uint32_t cnt = pr.y;                  // :446
     if (cnt == 1u) return false;                                                       // :448
-    uint32_t rank_a = step_idx - first;                                                // :452
+    uint32_t rank_a = (uint32_t)(step_idx - first);                                    // :452
     uint32_t rank_b = rank_a;
     if (a.it.cooling || rng.flip() == 1u) {                                            // :456
         bool back = false, fwd = false;
@@ -184,7 +199,7 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
 // the next B trips in advance, their record loads can be issued a trip ahead.
 // ------------------------------------------------------------------------------------------
 struct Leader {            // one sampled leader term (per lane, registers)
-    uint32_t first, cnt;   // PathInfo of its path
+    uint32_t first_lo, first_hi, cnt;   // PathInfo of its path (first_step is 64-bit)
     uint32_t ra0, rb0;     // ranks of step a and step b
     uint32_t ok;           // 0 = the reference `continue`d (cnt == 1 or rank_a == rank_b)
 };
@@ -192,11 +207,11 @@ struct Leader {            // one sampled leader term (per lane, registers)
 template <bool LDS_TABLES>
 __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng) {
     Leader L;
-    const uint32_t s0 = rng.uniform32(a.n_steps, a.steps_thresh);                      // sgd.rs:444
+    const uint64_t s0 = sample_step(a, rng);                                           // sgd.rs:444
     const uint4 r0 = a.step_rec[s0];
     const uint4 pr = path_tab[r0.y & 0x7FFFFFFFu];                                     // :445-446
-    L.first = pr.x; L.cnt = pr.y;
-    L.ra0 = s0 - pr.x; L.rb0 = L.ra0;                                                  // :452-453
+    L.first_lo = pr.x; L.first_hi = pr.w; L.cnt = pr.y;
+    L.ra0 = (uint32_t)(s0 - path_first(pr)); L.rb0 = L.ra0;                            // :452-453
     L.ok = 0;
     if (L.cnt == 1u) return L;                                                         // :448
     if (a.it.cooling || rng.flip() == 1u) {                                            // :456
@@ -221,8 +236,8 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
 // Expand leader values (already broadcast to this lane) into this lane's own term.
 // Returns false when the lane does not act in this trip.
 template <int B>
-__device__ __forceinline__ bool expand_run(uint32_t ok, uint32_t first, uint32_t cnt, uint32_t ra0, uint32_t rb0,
-                                           int sub, uint32_t &sa, uint32_t &sb) {
+__device__ __forceinline__ bool expand_run(uint32_t ok, uint64_t first, uint32_t cnt, uint32_t ra0, uint32_t rb0,
+                                           int sub, uint64_t &sa, uint64_t &sb) {
     if (!ok) return false;
     uint32_t ra_l = ra0, rb_l = rb0;
     if (sub != 0) {

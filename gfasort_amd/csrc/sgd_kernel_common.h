@@ -68,4 +68,9 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int leader_lane) {
 }
 
 
+template <int B>
+__device__ __forceinline__ uint64_t bcast_first(const Leader &L, int leader_lane) {
+    return ((uint64_t)bcast<B>(L.first_hi, leader_lane) << 32) | bcast<B>(L.first_lo, leader_lane);
+}
+
 }  // namespace gfs

@@ -27,7 +27,7 @@ __global__ void sgd1d_kernel(const KArgs a) {
         double *x = a.x;
         while (done < quota && att < max_att) {
             ++att;
-            uint4 ra, rb; uint32_t sa, sb, cnt, path;
+            uint4 ra, rb; uint64_t sa, sb; uint32_t cnt, path;
             if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) continue;
             double term_dist = fabs(rec_pos(ra) - rec_pos(rb));                        // sgd.rs:513
             if (term_dist == 0.0) continue;                                            // :514
@@ -109,19 +109,19 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
         ++passes;
         const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
         // trip 0: expand and request records
-        uint32_t sa = 0, sb = 0;
-        bool valid = expand_run<B>(bcast<B>(L.ok, q), bcast<B>(L.first, q), bcast<B>(L.cnt, q),
+        uint64_t sa = 0, sb = 0;
+        bool valid = expand_run<B>(bcast<B>(L.ok, q), bcast_first<B>(L, q), bcast<B>(L.cnt, q),
                                    bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, sa, sb);
         uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
         if (valid) { ra = a.step_rec[sa]; rb = a.step_rec[sb]; }
 #pragma unroll 2
         for (int t = 0; t < B; ++t) {
             // request the records of trip t+1
-            uint32_t sa_n = 0, sb_n = 0; bool valid_n = false;
+            uint64_t sa_n = 0, sb_n = 0; bool valid_n = false;
             uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = make_uint4(0, 0, 0, 0);
             if (t + 1 < B) {
                 const int ll = (t + 1) * RUNS + q;
-                valid_n = expand_run<B>(bcast<B>(L.ok, ll), bcast<B>(L.first, ll), bcast<B>(L.cnt, ll),
+                valid_n = expand_run<B>(bcast<B>(L.ok, ll), bcast_first<B>(L, ll), bcast<B>(L.cnt, ll),
                                         bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa_n, sb_n);
                 if (valid_n) { ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n]; }
             }

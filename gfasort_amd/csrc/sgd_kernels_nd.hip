@@ -29,10 +29,10 @@ __global__ void sgdnd_kernel(const KArgs a) {
         uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
         while (done < quota && att < max_att) {
             ++att;
-            uint4 ra, rb; uint32_t sa, sb, cnt, path;
+            uint4 ra, rb; uint64_t sa, sb; uint32_t cnt, path;
             if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) continue;
-            const uint32_t first = path_tab[path].x;
-            const uint32_t last_step = first + cnt - 1u;
+            const uint64_t first = path_first(path_tab[path]);
+            const uint64_t last_step = first + cnt - 1u;
             const uint64_t plen = a.path_len[path];
             uint64_t pa = ((uint64_t)ra.w << 32) | ra.z, pb = ((uint64_t)rb.w << 32) | rb.z;
             uint64_t na, nb;                       // position of the following step / path end

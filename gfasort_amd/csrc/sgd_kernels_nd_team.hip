@@ -40,8 +40,8 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
     while (wave_done < wave_quota && passes < max_passes) {
         ++passes;
         const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
-        uint32_t sa = 0, sb = 0;
-        uint32_t first = bcast<B>(L.first, q), cnt = bcast<B>(L.cnt, q);
+        uint64_t sa = 0, sb = 0;
+        uint64_t first = bcast_first<B>(L, q); uint32_t cnt = bcast<B>(L.cnt, q);
         bool valid = expand_run<B>(bcast<B>(L.ok, q), first, cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, sa, sb);
         uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, na = ra, nb = ra;
         if (valid) {
@@ -50,11 +50,11 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
         }
 #pragma unroll 2
         for (int t = 0; t < B; ++t) {
-            uint32_t sa_n = 0, sb_n = 0, first_n = 0, cnt_n = 0; bool valid_n = false;
+            uint64_t sa_n = 0, sb_n = 0, first_n = 0; uint32_t cnt_n = 0; bool valid_n = false;
             uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = ra_n, na_n = ra_n, nb_n = ra_n;
             if (t + 1 < B) {
                 const int ll = (t + 1) * RUNS + q;
-                first_n = bcast<B>(L.first, ll); cnt_n = bcast<B>(L.cnt, ll);
+                first_n = bcast_first<B>(L, ll); cnt_n = bcast<B>(L.cnt, ll);
                 valid_n = expand_run<B>(bcast<B>(L.ok, ll), first_n, cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa_n, sb_n);
                 if (valid_n) {
                     ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n];
@@ -66,7 +66,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
             double term_dist = 0.0;
             uint64_t idx_i = 0, idx_j = 0;
             if (valid) {
-                const uint32_t last_step = first + cnt - 1u;
+                const uint64_t last_step = first + cnt - 1u;
                 const uint64_t plen = a.path_len[ra.y & 0x7FFFFFFFu];
                 const uint64_t pa = ((uint64_t)ra.w << 32) | ra.z, pb = ((uint64_t)rb.w << 32) | rb.z;
                 const uint64_t ea = sa == last_step ? plen : (((uint64_t)na.w << 32) | na.z);

@@ -104,6 +104,8 @@ typedef struct gfs_launch_config {
 #define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* n in {0 = auto, 1, 4, 8, 16, 32, 64} */
 #define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
 #define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
+#define GFS_F_DBG_WIDE_INDEX 0x4000u  /* test hook: draw step indices with the u64 sampler that graphs of
+                                         more than 2^32-1 steps use (rand's usize sampler switches there) */
 
 typedef struct gfs_stats {
     uint64_t term_updates;            /* successful updates, counted where sgd.rs:579 counts */

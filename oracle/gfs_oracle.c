@@ -123,6 +123,18 @@ static inline uint64_t uniform_usize(uint64_t s[4], uint64_t n) {
     }
 }
 uint64_t gfo_uniform_usize(uint64_t s[4], uint64_t n) { return uniform_usize(s, n); }
+/* TEST HOOK: draw step indices with the u64 branch even when n <= u32::MAX, to exercise on small
+ * graphs the sampler that graphs of more than 2^32-1 steps use (the product's GFS_F_DBG_WIDE_INDEX). */
+static int g_force_wide_steps = 0;
+void gfo_set_force_wide_steps(int on) { g_force_wide_steps = on; }
+static inline uint64_t uniform_steps(uint64_t s[4], uint64_t n) {
+    if (!g_force_wide_steps) return uniform_usize(s, n);
+    uint64_t thresh = (0ull - n) % n;
+    for (;;) {
+        unsigned __int128 m = (unsigned __int128)xo_next(s) * n;
+        if ((uint64_t)m >= thresh) return (uint64_t)(m >> 64);
+    }
+}
 /* `Uniform::new(0, 2)` on default-i32: one u32 draw, wmul by 2, threshold 0 => top bit. */
 static inline uint32_t flip(uint64_t s[4]) { return (uint32_t)(xo_next(s) >> 63); }
 uint32_t gfo_flip(uint64_t s[4]) { return flip(s); }
@@ -317,7 +329,7 @@ static inline uint64_t space_index(const zipf_env *z, uint64_t jump_space) {
 static inline __attribute__((always_inline)) int
 sample_pair(const pidx *pi, const int flat, const zipf_env *z, const iter_state *it,
             uint64_t rng[4], uint64_t *sa, uint64_t *sb) {
-    uint64_t step_idx = uniform_usize(rng, pi->n_steps);              /* :444 */
+    uint64_t step_idx = uniform_steps(rng, pi->n_steps);              /* :444 */
     uint64_t path_idx, rank_a;
     if (flat) { path_idx = pi->rec[step_idx].path_rev & 0x7FFFFFFFu; }
     else      { path_idx = pi->step_to_path[step_idx]; }              /* :445 */
@@ -615,7 +627,7 @@ typedef struct { uint64_t first, cnt, ra0, rb0; int ok; } leader_t;
 static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t *rng) {
     const pidx *pi = &s->pi;
     leader_t L;
-    uint64_t s0 = uniform_usize(rng, pi->n_steps);                                     /* :444 */
+    uint64_t s0 = uniform_steps(rng, pi->n_steps);                                     /* :444 */
     uint64_t path = pi->rec[s0].path_rev & 0x7FFFFFFFu;
     L.first = pi->paths[path].first_step; L.cnt = pi->paths[path].step_count;
     L.ra0 = s0 - L.first; L.rb0 = L.ra0; L.ok = 0;

@@ -82,6 +82,7 @@ uint64_t gfo_splitmix64_next(uint64_t *state);
 void     gfo_xoshiro_seed(uint64_t seed, uint64_t s[4]);              /* seed_from_u64 */
 uint64_t gfo_xoshiro_next(uint64_t s[4]);                             /* xoshiro256+ next_u64 */
 uint64_t gfo_uniform_usize(uint64_t s[4], uint64_t n);                /* rand 0.9 Uniform<usize>(0,n) */
+void     gfo_set_force_wide_steps(int on);                            /* test hook, see gfs_oracle.c */
 uint32_t gfo_flip(uint64_t s[4]);                                     /* Uniform<i32>(0,2) */
 double   gfo_random_f64(uint64_t s[4]);                               /* rng.random::<f64>() */
 

@@ -589,3 +589,42 @@ def test_device_sort_and_device_path_index():
     ctx.upload(xs)
     assert np.array_equal(ctx.sort_order().astype(np.int64), np.argsort(xs + 0.0, kind="stable"))
     ctx.close()
+
+
+# ---- graphs beyond 2^32 steps use the u64 sampler and 64-bit step indices; exercised here on small graphs ------
+@pytest.mark.parametrize("bundle", [1, 16])
+def test_wide_index_path_matches_oracle(bundle):
+    """GFS_F_DBG_WIDE_INDEX draws step indices with rand's u64 branch (what n_steps > u32::MAX takes) and the
+    oracle is told to do the same: the sampled terms must still agree bit for bit."""
+    g = load("DRB1-3123.gfa")
+    p = _ygs(g, 5)
+    T, K = 256, 40
+    og, op = oracle_graph(g), oracle_params(p)
+    O.lib().gfo_set_force_wide_steps(1)
+    try:
+        st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=bundle)
+        x_ref = O.init_positions(og)
+        st_o.run(x_ref)
+        so = st_o.stats()
+        x1 = O.init_positions(og)
+        O.sgd_1d(og, op, x1, n_streams=1)
+    finally:
+        O.lib().gfo_set_force_wide_steps(0)
+    WIDE = 0x4000
+    ctx = hip.Context(g)
+    ctx.setup_1d(p, hip.make_config(n_streams=T, trace_per_stream=K, flags=hip.F_BUNDLE(bundle) | WIDE))
+    ctx.upload(hip.init_positions(g))
+    ctx.run()
+    tr, counts = ctx.trace()
+    hst = ctx.stats()
+    assert (hst.term_updates, hst.attempts) == (so.term_updates, so.attempts)
+    tr_ref = st_o.trace.reshape(T, K)
+    assert np.array_equal(tr["i"], tr_ref["i"]) and np.array_equal(tr["j"], tr_ref["j"])
+    ctx.close()
+    # and the single-stream replay in wide mode is bit-exact too
+    rc, x, st = hip.path_linear_sgd_raw(g, p, cfg=hip.make_config(n_streams=1, flags=WIDE))
+    assert np.array_equal(x.view(np.uint64), x1.view(np.uint64))
+    # the two samplers really differ
+    x32 = O.init_positions(og)
+    O.sgd_1d(og, op, x32, n_streams=1)
+    assert not np.array_equal(x32, x1)
