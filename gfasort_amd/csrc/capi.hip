@@ -20,6 +20,8 @@ hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool tr
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
+                           dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
                                    const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
                                    uint64_t n_steps, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len);
@@ -174,6 +176,8 @@ int gfs_sort_order(const double *x, uint64_t n, uint64_t *order) {         // sg
 // ---------------------------------------------------------------------------------------------
 // resident context
 // ---------------------------------------------------------------------------------------------
+static constexpr size_t kCounterBytes = 1024 * 8 * sizeof(unsigned long long);   // gfs::COUNTER_SLOTS lines of 64 B
+
 struct gfs_ctx {
     int device = 0;
     int cu_count = 0;
@@ -196,8 +200,10 @@ struct gfs_ctx {
     double *d_zetas = nullptr; uint64_t zlen_full = 0, zlen_staged = 0;
     double *d_x = nullptr; bool x_owned = false; uint64_t x_len = 0;
     uint64_t *d_rng = nullptr;
+    uint32_t *d_lead = nullptr;      // 1D team kernels: the waves' partly expanded passes, [6][n_streams]
     unsigned long long *d_counters = nullptr;
     gfs_term *d_trace = nullptr; uint32_t *d_trace_cnt = nullptr;
+    gfs::IterConsts *d_its = nullptr; uint64_t its_cap = 0;   // schedule slice of a fused launch
     uint64_t n_streams = 0, quota_total = 0;
     uint32_t block = 256;
     uint32_t bundle = 1;               // lanes per sampling bundle actually used (1 = reference streams)
@@ -208,6 +214,7 @@ struct gfs_ctx {
     size_t events_used = 0;
     double kernel_ms_harvested = 0.0;  // durations of event pairs already recycled
     uint64_t iterations = 0;
+    uint64_t launches = 0;
     double total_ms = 0.0;
 };
 
@@ -215,9 +222,13 @@ static void free_sgd_state(gfs_ctx *c) {
     if (c->d_zetas) (void)hipFree(c->d_zetas);
     if (c->d_x && c->x_owned) (void)hipFree(c->d_x);
     if (c->d_rng) (void)hipFree(c->d_rng);
+    if (c->d_lead) (void)hipFree(c->d_lead);
+    c->d_lead = nullptr;
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_trace) (void)hipFree(c->d_trace);
     if (c->d_trace_cnt) (void)hipFree(c->d_trace_cnt);
+    if (c->d_its) (void)hipFree(c->d_its);
+    c->d_its = nullptr; c->its_cap = 0;
     c->d_zetas = nullptr; c->d_x = nullptr; c->d_rng = nullptr; c->d_counters = nullptr;
     c->d_trace = nullptr; c->d_trace_cnt = nullptr; c->x_owned = false; c->configured = false;
 }
@@ -231,7 +242,7 @@ static int seed_streams(gfs_ctx *c) {
         for (int k = 0; k < 4; ++k) st[(uint64_t)k * T + t] = splitmix64(sm);
     }
     HIPCHK(hipMemcpy(c->d_rng, st.data(), st.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_counters, 0, kCounterBytes));
     if (c->d_trace_cnt) HIPCHK(hipMemset(c->d_trace_cnt, 0, T * sizeof(uint32_t)));
     c->events_used = 0; c->kernel_ms_harvested = 0.0; c->iterations = 0; c->total_ms = 0.0;
     return GFS_OK;
@@ -354,7 +365,11 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     c->lds_bytes = c->lds_tables ? lds : 0;
 
     HIPCHK(hipMalloc(&c->d_rng, 4 * T * 8));
-    HIPCHK(hipMalloc(&c->d_counters, 2 * sizeof(unsigned long long)));
+    if (dims == 0 && c->bundle > 1) {
+        HIPCHK(hipMalloc(&c->d_lead, 6 * T * sizeof(uint32_t)));
+        HIPCHK(hipMemset(c->d_lead, 0, 6 * T * sizeof(uint32_t)));      // trips left = 0: no pass yet
+    }
+    HIPCHK(hipMalloc(&c->d_counters, kCounterBytes));
     if (c->cfg.trace_per_stream) {
         HIPCHK(hipMalloc(&c->d_trace, T * c->cfg.trace_per_stream * sizeof(gfs_term)));
         HIPCHK(hipMemset(c->d_trace, 0, T * c->cfg.trace_per_stream * sizeof(gfs_term)));
@@ -561,20 +576,14 @@ int gfs_ctx_reset_streams(gfs_ctx *c) {
     if (!c || !c->d_rng) return fail(GFS_E_STATE, "context not set up");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
+    if (c->d_lead) HIPCHK(hipMemset(c->d_lead, 0, 6 * c->n_streams * sizeof(uint32_t)));
     return seed_streams(c);
 }
 
-int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
-    if (!c) return fail(GFS_E_ARG, "ctx is null");
-    if (!c->configured) return fail(GFS_E_STATE, "context not set up");
-    if (!c->valid_paths || c->n_nodes == 0) return GFS_NOTHING_TO_DO;
-    if (k > c->params.iter_max) return fail(GFS_E_ARG, "iteration beyond iter_max");
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)hip_stream;
-    gfs::KArgs a{};
+static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.step_rec = c->d_step_rec; a.path_rec = c->d_path_rec; a.path_len = c->d_path_len;
     a.zetas = c->d_zetas; a.x = c->d_x; a.rng = c->d_rng; a.counters = c->d_counters;
-    a.trace = c->d_trace; a.trace_cnt = c->d_trace_cnt;
+    a.trace = c->d_trace; a.trace_cnt = c->d_trace_cnt; a.lead = c->d_lead;
     a.n_steps = c->n_steps;
     const bool wide = c->n_steps > 0xFFFFFFFFull || (c->cfg.flags & GFS_F_DBG_WIDE_INDEX);
     a.steps_thresh = wide ? (0ull - c->n_steps) % c->n_steps
@@ -592,8 +601,9 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     a.dbg = (c->cfg.flags >> 8) & 0x7Fu;             // bit 0x40 = GFS_F_DBG_WIDE_INDEX >> 8
     if (4 * c->n_streams <= c->n_nodes) a.dbg |= 0x80u;      // team kernel: defer atomics by one trip
     a.bundle = c->bundle;
-    iter_consts(c, k, a.it);
-    dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
+}
+
+static int next_event_pair(gfs_ctx *c, std::pair<hipEvent_t, hipEvent_t> *&ev) {
     if (c->events_used == c->events.size()) {
         if (c->events.size() >= 4096) {
             // long-lived context: recycle the pool instead of growing it (one sync per 4096 launches)
@@ -609,14 +619,73 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
             c->events.emplace_back(e0, e1);
         }
     }
-    auto &ev = c->events[c->events_used++];
-    HIPCHK(hipEventRecord(ev.first, st));
+    ev = &c->events[c->events_used++];
+    return GFS_OK;
+}
+
+int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
+    if (!c) return fail(GFS_E_ARG, "ctx is null");
+    if (!c->configured) return fail(GFS_E_STATE, "context not set up");
+    if (!c->valid_paths || c->n_nodes == 0) return GFS_NOTHING_TO_DO;
+    if (k > c->params.iter_max) return fail(GFS_E_ARG, "iteration beyond iter_max");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    gfs::KArgs a{};
+    fill_kargs(c, a);
+    iter_consts(c, k, a.it);
+    dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    int rc = next_event_pair(c, ev);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev->first, st));
     hipError_t e = c->dims == 0
         ? gfs::launch_1d(a, c->lds_tables, c->atomic_loads, c->d_trace != nullptr, grid, block, c->lds_bytes, st)
         : gfs::launch_nd(c->dims, a, c->lds_tables, c->atomic_loads, c->d_trace != nullptr, grid, block, c->lds_bytes, st);
     if (e != hipSuccess) return fail(GFS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    HIPCHK(hipEventRecord(ev.second, st));
+    HIPCHK(hipEventRecord(ev->second, st));
     c->iterations++;
+    c->launches++;
+    return GFS_OK;
+}
+
+// A range of iterations ks[0..n) (each in 0..=iter_max).  On one GPU with the team kernel this is ONE
+// fused launch (sgd1d_team_fused_kernel); otherwise it falls back to one launch per iteration.
+int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stream) {
+    if (!c || (!ks && n)) return fail(GFS_E_ARG, "null argument");
+    if (!c->configured) return fail(GFS_E_STATE, "context not set up");
+    if (!c->valid_paths || c->n_nodes == 0) return GFS_NOTHING_TO_DO;
+    for (uint64_t i = 0; i < n; ++i) if (ks[i] > c->params.iter_max) return fail(GFS_E_ARG, "iteration beyond iter_max");
+    const bool can_fuse = c->dims == 0 && c->bundle >= 16 && c->atomic_loads && !c->d_trace && n > 1 && n <= 0xFFFFFFFFull &&
+                          !(c->cfg.flags & GFS_F_NO_FUSE);
+    if (!can_fuse) {
+        for (uint64_t i = 0; i < n; ++i) { int rc = gfs_ctx_run_iteration(c, ks[i], hip_stream); if (rc) return rc; }
+        return GFS_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    std::vector<gfs::IterConsts> its(n);
+    for (uint64_t i = 0; i < n; ++i) iter_consts(c, ks[i], its[i]);
+    if (c->its_cap < n) {
+        if (c->d_its) HIPCHK(hipFree(c->d_its));
+        c->d_its = nullptr; c->its_cap = 0;
+        HIPCHK(hipMalloc(&c->d_its, n * sizeof(gfs::IterConsts)));
+        c->its_cap = n;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_its, its.data(), n * sizeof(gfs::IterConsts), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                 // `its` is a stack-lifetime staging buffer
+    gfs::KArgs a{};
+    fill_kargs(c, a);
+    a.it = its[0];
+    dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    int rc = next_event_pair(c, ev);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev->first, st));
+    hipError_t e = gfs::launch_1d_fused(a, c->d_its, (uint32_t)n, c->lds_tables, grid, block, c->lds_bytes, st);
+    if (e != hipSuccess) return fail(GFS_E_HIP, std::string("fused kernel launch: ") + hipGetErrorString(e));
+    HIPCHK(hipEventRecord(ev->second, st));
+    c->iterations += n;
+    c->launches++;
     return GFS_OK;
 }
 
@@ -632,8 +701,10 @@ int gfs_ctx_run(gfs_ctx *c, void *hip_stream) {
     if (!c->configured) return fail(GFS_E_STATE, "context not set up");
     if (!c->valid_paths || c->n_nodes == 0) return GFS_NOTHING_TO_DO;
     auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t k = 0; k <= c->params.iter_max; ++k) {                   // iter_max+1 batches (sgd.rs:383)
-        int rc = gfs_ctx_run_iteration(c, k, hip_stream);
+    {
+        std::vector<uint64_t> ks(c->params.iter_max + 1);                  // iter_max+1 batches (sgd.rs:383)
+        std::iota(ks.begin(), ks.end(), (uint64_t)0);
+        int rc = gfs_ctx_run_range(c, ks.data(), ks.size(), hip_stream);
         if (rc) return rc;
     }
     int rc = gfs_ctx_synchronize(c, hip_stream);
@@ -648,16 +719,16 @@ int gfs_ctx_stats(gfs_ctx *c, gfs_stats *out) {
     if (!c->d_counters) return GFS_OK;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    unsigned long long cnt[2] = {0, 0};
-    HIPCHK(hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
-    out->term_updates = cnt[0]; out->attempts = cnt[1];
+    std::vector<unsigned long long> cnt(kCounterBytes / 8);
+    HIPCHK(hipMemcpy(cnt.data(), c->d_counters, kCounterBytes, hipMemcpyDeviceToHost));
+    for (size_t s = 0; s < cnt.size(); s += 8) { out->term_updates += cnt[s]; out->attempts += cnt[s + 1]; }
     out->iterations = c->iterations; out->n_streams = c->n_streams; out->bundle = c->bundle;
     double ms = c->kernel_ms_harvested;
     for (size_t k = 0; k < c->events_used; ++k) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, c->events[k].first, c->events[k].second) == hipSuccess) ms += t;
     }
-    out->kernel_ms = ms; out->total_ms = c->total_ms;
+    out->kernel_ms = ms; out->total_ms = c->total_ms; out->launches = c->launches;
     return GFS_OK;
 }
 

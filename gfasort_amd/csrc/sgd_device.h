@@ -92,9 +92,11 @@ struct KArgs {
     const double   *zetas;
     double         *x;             // 1D: x[n_nodes]; nD: coords[n_nodes*2*D] Layout order
     uint64_t       *rng;           // [4][n_streams] SoA
-    unsigned long long *counters;  // [0] successful updates, [1] attempts
+    unsigned long long *counters;  // [slots][8]: [s][0] successful updates, [s][1] attempts (sgd_kernel_common.h)
     void           *trace;         // gfs_term[n_streams*trace_per_stream] or null
     uint32_t       *trace_cnt;     // [n_streams]
+    uint32_t       *lead;          // [6][n_streams] SoA: leaders a 1D team wave has sampled but not yet expanded
+                                   // (first lo, first hi, cnt, ra0, rb0, ok | trips left << 8 | cooling << 16); or null
     uint64_t n_steps, steps_thresh;   // thresh = (2^w - n) mod n, w = 32 if n_steps <= u32::MAX else 64
     uint32_t n_paths, zlen_full;   // zlen_full: true table length (index clamp, sgd.rs:469)
     uint32_t zlen_staged;          // entries copied to LDS (>= every reachable index)

@@ -48,6 +48,8 @@ __device__ __forceinline__ void stage_tables(const KArgs &a, unsigned char *smem
     }
 }
 
+constexpr uint32_t COUNTER_SLOTS = 1024;     // counters: [COUNTER_SLOTS][8] u64, [s][0] = updates, [s][1] = attempts
+
 __device__ __forceinline__ void flush_counters(const KArgs &a, uint32_t done, uint32_t att) {
     // wave64 butterfly, one atomic per wave
     unsigned long long d = done, t = att;
@@ -56,8 +58,12 @@ __device__ __forceinline__ void flush_counters(const KArgs &a, uint32_t done, ui
         t += __shfl_xor(t, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&a.counters[0], d);
-        atomicAdd(&a.counters[1], t);
+        // one 64-byte line per slot, waves spread over COUNTER_SLOTS lines: thousands of atomics on ONE
+        // address serialise at the memory side and showed up as tens of microseconds at the end of every launch
+        const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        unsigned long long *slot = a.counters + (size_t)(wave & (COUNTER_SLOTS - 1)) * 8;
+        atomicAdd(slot, d);
+        atomicAdd(slot + 1, t);
     }
 }
 

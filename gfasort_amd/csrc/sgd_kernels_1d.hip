@@ -78,44 +78,49 @@ __global__ void sgd1d_kernel(const KArgs a) {
 // The quota is per WAVE with a rank cut-off in the last trip: an iteration performs exactly its
 // number of updates; leaders left over when the quota fills are discarded.
 // ------------------------------------------------------------------------------------------
-template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
-__global__ void sgd1d_team_kernel(const KArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const uint4 *path_tab; const double *zeta_tab;
-    stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
+// Per-wave state that survives from one iteration to the next inside a launch.
+struct TeamState {
+    Rng rng;
+    // the wave's current pass: 64 leaders (one per lane) of which `left` trips have not been expanded yet.
+    // A pass outlives the iteration it was sampled in (eta is not part of sampling); it is dropped when
+    // the cooling phase — the only thing the sampler depends on besides the RNG — changes.
+    Leader L = {0, 0, 0, 0, 0, 0};
+    uint32_t left = 0, cool = 0;
+    uint32_t done = 0, att = 0, ntr = 0;
+    bool pend = false; uint32_t pend_i = 0, pend_j = 0; double pend_r = 0.0;   // deferred atomics of the previous trip
+};
 
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;       // n_streams % 64 == 0 (host-checked)
-    if (tid >= a.n_streams) return;                                   // whole waves only
+// One SGD iteration of one wave: passes and trips until the wave's quota is filled.
+template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
+                                               TeamState &ts, const uint32_t tid, const uint64_t wave_quota) {
     const int lane = threadIdx.x & 63;
     const int sub = lane & (B - 1);
     const int q = lane / B;
     constexpr int RUNS = 64 / B;                                      // runs per trip
-    const uint64_t T = a.n_streams;
-    Rng rng;
-    rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid];
-    // wave quota = sum of its 64 lanes' per-stream quotas
-    const uint32_t wave_first = tid & ~63u;
-    uint64_t wave_quota = (uint64_t)a.quota_base * 64u;
-    if (wave_first < a.quota_rem) wave_quota += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
     const uint64_t max_passes = (uint64_t)a.attempt_factor * (wave_quota / (64u * B) + 1u) + 16u;
     uint64_t wave_done = 0, passes = 0;
-    uint32_t done = 0, att = 0;
-    uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
     double *x = a.x;
-    // deferred atomics of the previous trip
-    bool pend = false; uint32_t pend_i = 0, pend_j = 0; double pend_r = 0.0;
-
     while (wave_done < wave_quota && passes < max_passes) {
-        ++passes;
-        const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
-        // trip 0: expand and request records
+        if (ts.left == 0 || ts.cool != (uint32_t)a.it.cooling) {
+            ++passes;
+            ts.L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, ts.rng);
+            ts.left = B; ts.cool = (uint32_t)a.it.cooling;
+        }
+        const Leader &L = ts.L;
+        const int t0 = B - (int)ts.left;
+        // trip t0: expand and request records
         uint64_t sa = 0, sb = 0;
-        bool valid = expand_run<B>(bcast<B>(L.ok, q), bcast_first<B>(L, q), bcast<B>(L.cnt, q),
-                                   bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, sa, sb);
+        bool valid;
+        {
+            const int ll = t0 * RUNS + q;
+            valid = expand_run<B>(bcast<B>(L.ok, ll), bcast_first<B>(L, ll), bcast<B>(L.cnt, ll),
+                                  bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa, sb);
+        }
         uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
         if (valid) { ra = a.step_rec[sa]; rb = a.step_rec[sb]; }
 #pragma unroll 2
-        for (int t = 0; t < B; ++t) {
+        for (int t = t0; t < B; ++t) {
             // request the records of trip t+1
             uint64_t sa_n = 0, sb_n = 0; bool valid_n = false;
             uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = make_uint4(0, 0, 0, 0);
@@ -126,7 +131,8 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
                 if (valid_n) { ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n]; }
             }
             // consume trip t
-            ++att;
+            ++ts.att;
+            --ts.left;
             double term_dist = 0.0;
             uint32_t i = 0, j = 0;
             if (valid) {
@@ -148,11 +154,11 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
                 else { xi = load_pos<ATOMIC_LOADS>(x + i); xj = load_pos<ATOMIC_LOADS>(x + j); }   // :541-542
             }
             if (DEFER) {
-                if (pend) {
-                    if (a.dbg & 1u) { asm volatile("" :: "v"(pend_r), "v"(pend_i), "v"(pend_j)); }   // ablation: no atomics
-                    else { add_pos(x + pend_i, -pend_r); add_pos(x + pend_j, pend_r); }   // trip t-1's :575-576
+                if (ts.pend) {
+                    if (a.dbg & 1u) { asm volatile("" :: "v"(ts.pend_r), "v"(ts.pend_i), "v"(ts.pend_j)); }   // ablation: no atomics
+                    else { add_pos(x + ts.pend_i, -ts.pend_r); add_pos(x + ts.pend_j, ts.pend_r); }   // trip t-1's :575-576
                 }
-                pend = valid;
+                ts.pend = valid;
             }
             if (valid) {
                 double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                   // :518-520
@@ -161,25 +167,94 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
                 double mag = fabs(dx);                                                 // :551
                 double delta = mu * (mag - term_dist) / 2.0;                           // :552
                 double r = delta / mag;                                                // :570
-                pend_r = r * dx; pend_i = i; pend_j = j;                               // :571
-                if (!DEFER) { add_pos(x + i, -pend_r); add_pos(x + j, pend_r); }       // :575-576
-                ++done;                                                                // :579
+                ts.pend_r = r * dx; ts.pend_i = i; ts.pend_j = j;                      // :571
+                if (!DEFER) { add_pos(x + i, -ts.pend_r); add_pos(x + j, ts.pend_r); } // :575-576
+                ++ts.done;                                                             // :579
                 if (TRACE) {
-                    if (ntr < a.trace_per_stream) {
-                        TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                    if (ts.ntr < a.trace_per_stream) {
+                        TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ts.ntr;
                         tt->i = i; tt->j = j; tt->d = term_dist;
-                        ++ntr;
+                        ++ts.ntr;
                     }
                 }
             }
-            if (wave_done >= wave_quota) break;                                        // leaders left over are discarded
+            if (wave_done >= wave_quota) break;                                        // leaders left over serve the next iteration
             ra = ra_n; rb = rb_n; sa = sa_n; sb = sb_n; valid = valid_n;
         }
     }
-    if (pend) { add_pos(x + pend_i, -pend_r); add_pos(x + pend_j, pend_r); }
-    a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;
-    if (TRACE) a.trace_cnt[tid] = ntr;
-    flush_counters(a, done, att);
+}
+
+__device__ __forceinline__ void load_pass(const KArgs &a, uint32_t tid, TeamState &ts) {
+    if (!a.lead) return;
+    const uint64_t T = a.n_streams;
+    ts.L.first_lo = a.lead[tid]; ts.L.first_hi = a.lead[T + tid]; ts.L.cnt = a.lead[2 * T + tid];
+    ts.L.ra0 = a.lead[3 * T + tid]; ts.L.rb0 = a.lead[4 * T + tid];
+    const uint32_t w = a.lead[5 * T + tid];
+    ts.L.ok = w & 1u; ts.left = (w >> 8) & 0xFFu; ts.cool = (w >> 16) & 1u;
+}
+__device__ __forceinline__ void store_pass(const KArgs &a, uint32_t tid, const TeamState &ts) {
+    if (!a.lead) return;
+    const uint64_t T = a.n_streams;
+    a.lead[tid] = ts.L.first_lo; a.lead[T + tid] = ts.L.first_hi; a.lead[2 * T + tid] = ts.L.cnt;
+    a.lead[3 * T + tid] = ts.L.ra0; a.lead[4 * T + tid] = ts.L.rb0;
+    a.lead[5 * T + tid] = (ts.L.ok & 1u) | (ts.left << 8) | (ts.cool << 16);
+}
+
+__device__ __forceinline__ uint64_t wave_quota_of(const KArgs &a, uint32_t tid) {
+    // wave quota = sum of its 64 lanes' per-stream quotas
+    const uint32_t wave_first = tid & ~63u;
+    uint64_t wq = (uint64_t)a.quota_base * 64u;
+    if (wave_first < a.quota_rem) wq += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
+    return wq;
+}
+
+template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__global__ void sgd1d_team_kernel(const KArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;       // n_streams % 64 == 0 (host-checked)
+    if (tid >= a.n_streams) return;                                   // whole waves only
+    const uint64_t T = a.n_streams;
+    TeamState ts;
+    ts.rng.s0 = a.rng[tid]; ts.rng.s1 = a.rng[T + tid]; ts.rng.s2 = a.rng[2 * T + tid]; ts.rng.s3 = a.rng[3 * T + tid];
+    ts.ntr = TRACE ? a.trace_cnt[tid] : 0;
+    load_pass(a, tid, ts);
+    team_iteration<B, DEFER, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wave_quota_of(a, tid));
+    if (ts.pend) { add_pos(a.x + ts.pend_i, -ts.pend_r); add_pos(a.x + ts.pend_j, ts.pend_r); }
+    a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;
+    if (TRACE) a.trace_cnt[tid] = ts.ntr;
+    store_pass(a, tid, ts);
+    flush_counters(a, ts.done, ts.att);
+}
+
+// K1c: the same, FUSED over a range of iterations (single-GPU runs): one persistent launch in which
+// every wave walks the schedule its[0..n_iters) and performs its exact per-iteration quota under each
+// iteration's constants.  No grid barrier separates iterations — the reference's boundaries are looser
+// still (a 1 ms polling thread, sgd.rs:366-403) — but every iteration still applies exactly
+// min_term_updates updates with its own eta/theta.  Saves the per-launch ramp, tail and RNG round trip.
+template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS>
+__global__ void sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a0, smem, path_tab, zeta_tab);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= a0.n_streams) return;
+    const uint64_t T = a0.n_streams;
+    KArgs a = a0;
+    TeamState ts;
+    ts.rng.s0 = a.rng[tid]; ts.rng.s1 = a.rng[T + tid]; ts.rng.s2 = a.rng[2 * T + tid]; ts.rng.s3 = a.rng[3 * T + tid];
+    const uint64_t wq = wave_quota_of(a, tid);
+    load_pass(a, tid, ts);
+    for (uint32_t k = 0; k < n_iters; ++k) {
+        a.it = its[k];                                                // wave-uniform: scalar loads
+        team_iteration<B, DEFER, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq);
+        // same flush point as the per-iteration kernel: a single wave gives bit-identical results either way
+        if (DEFER && ts.pend) { add_pos(a.x + ts.pend_i, -ts.pend_r); add_pos(a.x + ts.pend_j, ts.pend_r); ts.pend = false; }
+    }
+    a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;
+    store_pass(a, tid, ts);
+    flush_counters(a, ts.done, ts.att);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -249,6 +324,31 @@ static hipError_t launch_1db(const KArgs &a, bool lds_tables, bool atomic_loads,
     return atomic_loads ? launch_1db_t<B, false, true>(a, trace, grid, block, 0, st)
                         : launch_1db_t<B, false, false>(a, trace, grid, block, 0, st);
 }
+template <int B>
+static hipError_t launch_1d_fused_b(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
+                                    dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    const bool defer = (a.dbg & 0x80u) != 0;
+    if (lds_tables) {
+        if (defer) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, true, true>), grid, block, lds, st, a, d_its, n_iters);
+        else       hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, true, true>), grid, block, lds, st, a, d_its, n_iters);
+    } else {
+        if (defer) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, false, true>), grid, block, 0, st, a, d_its, n_iters);
+        else       hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, false, true>), grid, block, 0, st, a, d_its, n_iters);
+    }
+    return hipGetLastError();
+}
+// fused range of iterations; only for the team kernel with its widest bundles (what the auto policy picks
+// on graphs large enough for launch overhead to matter)
+hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
+                           dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    switch (a.bundle) {
+        case 16: return launch_1d_fused_b<16>(a, d_its, n_iters, lds_tables, grid, block, lds, st);
+        case 32: return launch_1d_fused_b<32>(a, d_its, n_iters, lds_tables, grid, block, lds, st);
+        case 64: return launch_1d_fused_b<64>(a, d_its, n_iters, lds_tables, grid, block, lds, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
                      dim3 grid, dim3 block, size_t lds, hipStream_t st) {
     switch (a.bundle) {

@@ -150,10 +150,35 @@ class ShardedSGD:
         if self.world > 1:
             self.x_prev.copy_(self.engine.positions)
 
+    def _merge_due(self, k: int) -> bool:
+        return self.world > 1 and ((k + 1) % self.merge_every == 0 or k == int(self.params.iter_max))
+
     def run_iteration(self, k: int):
         self.engine.run_iteration(k)
-        last = k == int(self.params.iter_max)
-        if self.world > 1 and ((k + 1) % self.merge_every == 0 or last):
+        self._merge_if_due(k)
+
+    def run_range(self, ks):
+        """Iterations ks in order; the iterations between two merges go to the engine as one range
+        (one fused persistent launch on the HIP engine)."""
+        seg = []
+        for k in ks:
+            seg.append(int(k))
+            if self._merge_due(int(k)):
+                self._run_segment(seg)
+                self._merge_if_due(int(k))
+                seg = []
+        if seg:
+            self._run_segment(seg)
+
+    def _run_segment(self, seg):
+        if hasattr(self.engine, "run_range"):
+            self.engine.run_range(seg)
+        else:
+            for k in seg:
+                self.engine.run_iteration(k)
+
+    def _merge_if_due(self, k: int):
+        if self._merge_due(k):
             torch = self._torch
             x = self.engine.positions
             n = x.shape[0]
@@ -176,8 +201,7 @@ class ShardedSGD:
                 x.copy_(self.x_prev)
 
     def run(self):
-        for k in range(int(self.params.iter_max) + 1):
-            self.run_iteration(k)
+        self.run_range(range(int(self.params.iter_max) + 1))
 
     def positions_numpy(self) -> np.ndarray:
         """Positions in the ABI's dense-index order."""
@@ -224,6 +248,10 @@ class HipEngine:
     def run_iteration(self, k):
         stream = self._torch.cuda.current_stream(self.device).cuda_stream
         return self.ctx.run_iteration(k, stream)
+
+    def run_range(self, ks):
+        stream = self._torch.cuda.current_stream(self.device).cuda_stream
+        return self.ctx.run_range(ks, stream)
 
     def stats(self):
         return self.ctx.stats()

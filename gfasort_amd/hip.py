@@ -11,7 +11,7 @@ from . import build as _build
 NO_NODE = 0xFFFFFFFF
 MAX_DIMS = 8
 OK, NOTHING_TO_DO = 0, 1
-F_PLAIN_LOADS, F_NO_LDS_TABLES = 1, 2
+F_PLAIN_LOADS, F_NO_LDS_TABLES, F_NO_FUSE = 1, 2, 4
 
 
 def F_BUNDLE(n):
@@ -53,7 +53,7 @@ class LaunchConfig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("term_updates", C.c_uint64), ("attempts", C.c_uint64), ("iterations", C.c_uint64),
                 ("n_streams", C.c_uint64), ("bundle", C.c_uint64), ("kernel_ms", C.c_double),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("launches", C.c_uint64)]
 
 
 TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)
@@ -66,7 +66,7 @@ EXPORTS = [
     "gfs_ctx_create_with_layout", "gfs_ctx_node_layout",
     "gfs_ctx_destroy", "gfs_ctx_setup_1d", "gfs_ctx_setup_nd", "gfs_ctx_positions_len",
     "gfs_ctx_upload_positions", "gfs_ctx_download_positions", "gfs_ctx_positions_device",
-    "gfs_ctx_bind_positions", "gfs_ctx_reset_streams", "gfs_ctx_run_iteration", "gfs_ctx_run",
+    "gfs_ctx_bind_positions", "gfs_ctx_reset_streams", "gfs_ctx_run_iteration", "gfs_ctx_run_range", "gfs_ctx_run",
     "gfs_ctx_synchronize", "gfs_ctx_stats", "gfs_ctx_sort_order", "gfs_ctx_trace", "gfs_merge_prepare", "gfs_merge_apply",
 ]
 
@@ -99,6 +99,7 @@ def lib():
         L.gfs_ctx_destroy.restype = None
         L.gfs_ctx_run_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.gfs_ctx_run.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_ctx_run_range.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.gfs_ctx_synchronize.argtypes = [C.c_void_p, C.c_void_p]
         L.gfs_ctx_bind_positions.argtypes = [C.c_void_p, C.c_void_p]
         L.gfs_ctx_reset_streams.argtypes = [C.c_void_p]
@@ -278,6 +279,11 @@ class Context:
 
     def run_iteration(self, k, stream=None):
         return check(lib().gfs_ctx_run_iteration(self._h, C.c_uint64(k), C.c_void_p(stream or 0)))
+
+    def run_range(self, ks, stream=None):
+        """Iterations ks (a fused persistent launch where possible)."""
+        ks = np.ascontiguousarray(ks, dtype=np.uint64)
+        return check(lib().gfs_ctx_run_range(self._h, _ptr(ks), C.c_uint64(ks.shape[0]), C.c_void_p(stream or 0)))
 
     def run(self, stream=None):
         return check(lib().gfs_ctx_run(self._h, C.c_void_p(stream or 0)))

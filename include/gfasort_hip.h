@@ -102,6 +102,8 @@ typedef struct gfs_launch_config {
  * reference worker thread.  n = 0 (default): the library picks by graph size — 1 for small
  * graphs, up to 64 when an iteration still has >= 65536 independent bundle draws.            */
 #define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* n in {0 = auto, 1, 4, 8, 16, 32, 64} */
+#define GFS_F_NO_FUSE       4u        /* gfs_ctx_run / gfs_ctx_run_range: one launch per iteration even where
+                                         a fused persistent launch is possible                        */
 #define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
 #define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
 #define GFS_F_DBG_WIDE_INDEX 0x4000u  /* test hook: draw step indices with the u64 sampler that graphs of
@@ -115,6 +117,7 @@ typedef struct gfs_stats {
     uint64_t bundle;                  /* lanes per sampling bundle actually used (1 = reference streams) */
     double   kernel_ms;               /* sum of SGD kernel durations (HIP events)            */
     double   total_ms;                /* wall time inside the call (one-shot) / run          */
+    uint64_t launches;                /* SGD kernel launches (a fused launch covers many iterations) */
 } gfs_stats;
 
 /* One sampled term (debug trace): 1D i,j = dense node index; nD = 2*idx+end. */
@@ -190,7 +193,10 @@ int   gfs_ctx_reset_streams(gfs_ctx *ctx);                       /* re-seed RNG 
  * k > floor(cooling_start*iter_max) (sgd.rs:297,383-396).  Asynchronous on hip_stream
  * (a hipStream_t, NULL = the default stream).                                               */
 int   gfs_ctx_run_iteration(gfs_ctx *ctx, uint64_t k, void *hip_stream);
-int   gfs_ctx_run(gfs_ctx *ctx, void *hip_stream);               /* k = 0..=iter_max, then sync */
+/* iterations ks[0..n): on one GPU with the team kernel ONE fused persistent launch in which every wave
+ * walks the schedule with its exact per-iteration quota; otherwise n launches.  Asynchronous.       */
+int   gfs_ctx_run_range(gfs_ctx *ctx, const uint64_t *ks, uint64_t n, void *hip_stream);
+int   gfs_ctx_run(gfs_ctx *ctx, void *hip_stream);               /* k = 0..=iter_max (run_range), then sync */
 int   gfs_ctx_synchronize(gfs_ctx *ctx, void *hip_stream);
 int   gfs_ctx_stats(gfs_ctx *ctx, gfs_stats *out);               /* synchronises                */
 /* rank order of the context's current 1D positions, sorted on the device (rocPRIM radix sort)   */

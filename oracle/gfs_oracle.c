@@ -526,6 +526,7 @@ struct gfo_state {
     zipf_env z;
     uint64_t T, D, quota_total, attempt_factor, bundle;
     uint64_t *rng, *done, *att, *ntr;
+    struct leader_s *lead; uint8_t *lead_left, *lead_cool;   /* 1D bundled mode: each wave's partly expanded pass */
     gfo_term *trace; uint64_t trace_per_stream;
     uint64_t total_upd, total_att, iterations;
     double seconds;
@@ -535,6 +536,7 @@ void gfo_state_destroy(gfo_state *s) {
     if (!s) return;
     pidx_free(&s->pi);
     free(s->etas); free(s->zetas); free(s->rng); free(s->done); free(s->att); free(s->ntr);
+    free(s->lead); free(s->lead_left); free(s->lead_cool);
     free(s);
 }
 
@@ -621,7 +623,7 @@ static int term_nd_flips(const pidx *pi, const iter_state *it, int fa, int fb, u
     return 1;
 }
 
-typedef struct { uint64_t first, cnt, ra0, rb0; int ok; } leader_t;
+typedef struct leader_s { uint64_t first, cnt, ra0, rb0; int ok; } leader_t;
 
 /* one leader term from one reference stream: sgd.rs:444-497 without applying it */
 static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t *rng) {
@@ -655,7 +657,9 @@ static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t
 
 /* Team semantics of the product (sgd1d_team_kernel): per wave of 64 streams, a PASS samples one
  * leader per stream; B TRIPS then expand the 64 leaders as 64/B runs of B lanes (trip t, run q
- * uses leader t*(64/B)+q).  Wave-level quota with a rank cut-off; leftover leaders are dropped. */
+ * uses leader t*(64/B)+q).  Wave-level quota with a rank cut-off.  1D: the trips of a pass left over when
+ * the quota fills serve the next iteration (dropped only when the cooling phase, which the sampler depends
+ * on, changes); nD (sgdnd_team_kernel): leftover leaders are dropped. */
 static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
     const uint64_t T = s->T, B = s->bundle, RUNS = 64 / B;
     const pidx *pi = &s->pi;
@@ -667,11 +671,20 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
         if (wave_first < rem) wave_quota += (rem - wave_first) < 64 ? (rem - wave_first) : 64;
         const uint64_t max_passes = s->attempt_factor * (wave_quota / (64 * B) + 1) + 16;
         uint64_t wave_done = 0, passes = 0;
+        const int carry = s->D == 0;
+        if (!s->lead) {
+            s->lead = (leader_t *)calloc(T, sizeof(leader_t));
+            s->lead_left = (uint8_t *)calloc(T / 64, 1); s->lead_cool = (uint8_t *)calloc(T / 64, 1);
+        }
+        leader_t *L = s->lead + wave_first;
         while (wave_done < wave_quota && passes < max_passes) {
-            passes++;
-            leader_t L[64];
-            for (int l = 0; l < 64; l++) L[l] = sample_leader(s, &it, s->rng + 4 * (wave_first + l));
-            for (uint64_t t = 0; t < B && wave_done < wave_quota; t++) {
+            if (!carry || s->lead_left[w] == 0 || s->lead_cool[w] != (uint8_t)it.cooling) {
+                passes++;
+                for (int l = 0; l < 64; l++) L[l] = sample_leader(s, &it, s->rng + 4 * (wave_first + l));
+                s->lead_left[w] = (uint8_t)B; s->lead_cool[w] = (uint8_t)it.cooling;
+            }
+            for (uint64_t t = B - s->lead_left[w]; t < B && wave_done < wave_quota; t++) {
+                s->lead_left[w]--;
                 int valid[64], flips_a[64], flips_b[64]; uint64_t sa[64], sb[64];
                 uint64_t nvalid = 0;
                 for (uint64_t qq = 0; qq < RUNS; qq++) {

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of scripts/profile.sh (gpurun_out/prof/<tag>/) into the small files kept
+under profiles/: <prefix>_kernel_stats.csv (the --stats table), <prefix>_pmc_summary.csv (per-launch and
+per-SGD-iteration means of every counter, per kernel) and profiles/traffic_latest.json (what bench.py
+reports as roofline.traffic).
+
+A fused launch covers many iterations, so counters are also normalised per iteration: the SGD kernels'
+the fused kernel's single dispatch is bench.py's timed region (--steps iterations; bench.py warms up with
+per-iteration launches), every dispatch of the other kernels is one iteration.
+
+usage: summarize_profile.py gpurun_out/prof/<tag> profiles/r01/<prefix> --steps 20 --warmup 3 [--updates 10000000]
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.replace("void ", "").replace("gfs::", "")
+    return n.split("(")[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("dst_prefix")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--updates", type=float, default=1e7, help="term updates per iteration")
+    args = ap.parse_args()
+
+    ks = glob.glob(os.path.join(args.src, "trace", "*", "*_kernel_stats.csv"))
+    if ks:
+        shutil.copy(ks[0], args.dst_prefix + "_kernel_stats.csv")
+    bj = os.path.join(args.src, "bench_trace.json")
+    if os.path.exists(bj):
+        shutil.copy(bj, args.dst_prefix + "_bench_under_rocprof.json")
+
+    rows = []
+    per_iter = {}
+    for d in sorted(glob.glob(os.path.join(args.src, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        # (kernel, counter) -> list of (dispatch id, value); a counter may be reported once per dimension: sum
+        acc = defaultdict(lambda: defaultdict(float))
+        with open(files[0]) as fh:
+            for r in csv.DictReader(fh):
+                k = short(r["Kernel_Name"])
+                if "sgd" not in k:
+                    continue
+                acc[(k, r["Counter_Name"])][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+        for (k, c), disp in sorted(acc.items()):
+            vals = [disp[i] for i in sorted(disp)]
+            fused = "fused" in k
+            if fused:
+                its = {1: [args.steps], 2: [args.warmup, args.steps]}.get(len(vals))
+            else:
+                its = [1] * len(vals)
+            mean = sum(vals) / len(vals)
+            piter = sum(vals) / sum(its) if its else float("nan")
+            rows.append((k, os.path.basename(d), c, len(vals), mean, min(vals), max(vals), piter))
+            per_iter[(k, c)] = piter
+
+    with open(args.dst_prefix + "_pmc_summary.csv", "w") as fh:
+        fh.write("kernel,pass,counter,dispatches,mean_per_launch,min,max,mean_per_sgd_iteration\n")
+        for r in rows:
+            fh.write("%s,%s,%s,%d,%.6g,%.6g,%.6g,%.6g\n" % r)
+
+    # traffic of the dominant (team) kernel
+    team = [k for (k, c) in per_iter if "team" in k and c == "FETCH_SIZE"]
+    if team:
+        k = sorted(team, key=lambda s: "fused" not in s)[0]
+        fetch_kb = per_iter[(k, "FETCH_SIZE")]
+        write_kb = per_iter.get((k, "WRITE_SIZE"), float("nan"))
+        hbm = (2.0 * fetch_kb + write_kb) * 1024.0
+        out = {
+            "kernel": k,
+            "source": os.path.basename(args.dst_prefix) + "_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
+                      "separate passes, bench.py --steps %d --warmup %d)" % (args.steps, args.warmup),
+            "fetch_size_kb_per_iteration": fetch_kb,
+            "write_size_kb_per_iteration": write_kb,
+            "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B: confirmed on a streaming read and on "
+                          "1-KB record runs, profiles/r01/fetch_calibration.txt); WRITE_SIZE as reported",
+            "term_updates_per_iteration": args.updates,
+            "hbm_bytes_per_update": hbm / args.updates,
+            "algorithmic_bytes_per_update": 64,
+        }
+        root = os.path.dirname(os.path.dirname(os.path.abspath(args.dst_prefix)))
+        with open(os.path.join(root, "traffic_latest.json"), "w") as fh:
+            json.dump(out, fh, indent=1)
+        print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

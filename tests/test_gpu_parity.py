@@ -628,3 +628,47 @@ def test_wide_index_path_matches_oracle(bundle):
     x32 = O.init_positions(og)
     O.sgd_1d(og, op, x32, n_streams=1)
     assert not np.array_equal(x32, x1)
+
+
+# ---- fused persistent launch (gfs_ctx_run_range) -------------------------------------------------------------
+@pytest.mark.parametrize("bundle", [16, 64])
+def test_fused_launch_equals_per_iteration_launches_on_one_wave(bundle):
+    """One wave is deterministic, and the fused kernel keeps the per-iteration kernel's flush points: the whole
+    run in ONE launch gives bit-identical positions, counters and RNG consumption to one launch per iteration."""
+    g = G.synth_windows(20_000, 8, 10_000, 5)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 12
+    out = []
+    for extra in (0, hip.F_NO_FUSE):
+        ctx = hip.Context(g)
+        ctx.setup_1d(p, hip.make_config(n_streams=64, flags=hip.F_BUNDLE(bundle) | extra))
+        ctx.upload(hip.init_positions(g))
+        ctx.run()
+        st = ctx.stats()
+        out.append((ctx.download(), st))
+        ctx.close()
+    (xf, sf), (xu, su) = out
+    assert (sf.launches, su.launches) == (1, 13) and sf.iterations == su.iterations == 13
+    assert (sf.term_updates, sf.attempts) == (su.term_updates, su.attempts) and sf.term_updates == 13 * p.min_term_updates
+    assert np.array_equal(xf.view(np.uint64), xu.view(np.uint64))
+
+
+def test_fused_range_with_repeated_and_partial_schedules():
+    """run_range takes any list of iteration numbers; counts stay exact and a range that cannot be fused
+    (reference streams) falls back to per-iteration launches."""
+    g = G.synth_windows(50_000, 8, 25_000, 6)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 20
+    for bundle, want_launches in ((64, 2), (1, 12)):
+        ctx = hip.Context(g)
+        ctx.setup_1d(p, hip.make_config(flags=hip.F_BUNDLE(bundle)))
+        ctx.upload(hip.init_positions(g))
+        ctx.run_range([0, 1, 2, 3, 4])
+        ctx.run_range([5, 6, 7, 20, 20, 0, 1])
+        ctx.synchronize()
+        st = ctx.stats()
+        assert st.launches == want_launches and st.iterations == 12 and st.term_updates == 12 * p.min_term_updates
+        assert np.isfinite(ctx.download()).all()
+        with pytest.raises(Exception):
+            ctx.run_range([21])
+        ctx.close()
