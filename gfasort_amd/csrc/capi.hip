@@ -22,6 +22,10 @@ hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_load
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
                            dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t warm_module_1d();
+hipError_t warm_module_nd();
+hipError_t warm_module_nd_team();
+hipError_t warm_module_index();
 hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
                                    const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
                                    uint64_t n_steps, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len);
@@ -94,6 +98,14 @@ int gfs_warmup(int device) {
     if (device < 0 || device >= n) return fail(GFS_E_ARG, "bad device index");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
+    // code objects load on first use, one per translation unit: touch each now, and the allocator too
+    HIPCHK(gfs::warm_module_1d());
+    HIPCHK(gfs::warm_module_nd());
+    HIPCHK(gfs::warm_module_nd_team());
+    HIPCHK(gfs::warm_module_index());
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, 1 << 20));
+    HIPCHK(hipFree(p));
     return GFS_OK;
 }
 

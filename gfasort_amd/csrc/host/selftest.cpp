@@ -119,6 +119,69 @@ int main(int argc, char **argv) {
         REQUIRE(l.num_nodes == 0 && l.dimensions == 2);
         std::cout << "ok empty\n";
     }
+    {   // the reader's path-step tokenizer: trims, skips empty tokens, cuts long lists into pieces (any thread count)
+        std::string small = "S\t1\tA\nS\t2\tC\nS\t3\tG\nP\tp\t1+,, 2- ,3+ ,\t*\nP\tempty\t\t*\nP\tq\t3x,+2+\t*\n";
+        for (size_t nt : {1, 3}) {
+            set_io_threads(nt);
+            BidirectedGraph g = parse_gfa(small);
+            REQUIRE(g.paths.size() == 3 && g.paths[1].steps.empty());
+            REQUIRE((g.paths[0].steps == std::vector<Handle>{Handle::forward(1), Handle::reverse(2), Handle::forward(3)}));
+            // any last character other than '+' reads as reverse; a leading '+' is part of the number (usize::from_str)
+            REQUIRE((g.paths[2].steps == std::vector<Handle>{Handle::reverse(3), Handle::forward(2)}));
+            std::ostringstream out; g.write_gfa(out);
+            REQUIRE(out.str().find("P\tp\t1+,2-,3+\t*\nP\tempty\t\t*\nP\tq\t3-,2+\t*\n") != std::string::npos);
+            // 700k steps (several pieces), an empty token in every 1000th place so that pieces have to be closed up
+            std::string big = "S\t1\tA\nP\tlong\t";
+            std::vector<Handle> want;
+            for (size_t k = 0; k < 700000; ++k) {
+                size_t id = 1 + (k * 2654435761u) % 999983;
+                bool rev = (k % 7) == 3;
+                big += std::to_string(id); big += rev ? '-' : '+'; big += ',';
+                if (k % 1000 == 999) big += " ,";
+                want.push_back(Handle::make(id, rev));
+            }
+            big += "\t*\n";
+            BidirectedGraph gb = parse_gfa(big);
+            REQUIRE(gb.paths.size() == 1 && gb.paths[0].steps == want);
+            FlatGraph f = gb.flatten();
+            REQUIRE(f.step_node.size() == want.size() && f.step_is_rev[3] == 1 && f.step_node[0] == 0 && f.step_node[1] == GFS_NO_NODE);
+            std::ostringstream ob; gb.write_gfa(ob);
+            BidirectedGraph gb2 = parse_gfa(ob.str());
+            REQUIRE(gb2.paths[0].steps == want);
+            // a bad token in a late piece is reported with the reference's text
+            std::string bad = big; bad.replace(bad.size() - 20, 1, "x");
+            bool threw = false;
+            try { (void)parse_gfa(bad); } catch (const std::exception &e) {
+                threw = std::string(e.what()) == "Failed to parse path node ID: invalid digit found in string";
+            }
+            REQUIRE(threw);
+            threw = false;
+            try { (void)parse_gfa("P\tp\t99999999999999999999+\t*\n"); } catch (const std::exception &e) {
+                threw = std::string(e.what()) == "Failed to parse path node ID: number too large to fit in target type";
+            }
+            REQUIRE(threw);
+            REQUIRE(parse_gfa("P\tp\t18446744073709551615+\t*\n").paths[0].steps.size() == 1);   // u64::MAX parses
+        }
+        set_io_threads(0);
+        std::cout << "ok tokenizer\n";
+    }
+    {   // EdgeSet: set semantics under growth, complement rule of add_edge, ordered L lines
+        BidirectedGraph g;
+        std::vector<BiEdge> list;
+        for (size_t k = 1; k <= 5000; ++k) {
+            list.push_back(BiEdge{Handle::forward(k), Handle::forward(k + 1)});
+            list.push_back(BiEdge{Handle::reverse(k + 1), Handle::reverse(k)});      // complement: not added
+            list.push_back(BiEdge{Handle::forward(k), Handle::forward(k + 1)});      // duplicate
+        }
+        g.add_edges(list);
+        REQUIRE(g.edges.size() == 5000);
+        size_t seen = 0;
+        for (const BiEdge &e : g.edges) { REQUIRE(e.to.node_id() == e.from.node_id() + 1); ++seen; }
+        REQUIRE(seen == 5000 && g.has_edge(Handle::reverse(78), Handle::reverse(77)) && !g.has_edge(Handle::forward(78), Handle::forward(77)));
+        std::ostringstream out; g.write_gfa(out);
+        REQUIRE(out.str().find("L\t1\t+\t2\t+\t0M\nL\t2\t+\t3\t+\t0M\n") != std::string::npos);
+        std::cout << "ok edges\n";
+    }
     std::cout << "ALL OK\n";
     return 0;
 }

@@ -109,4 +109,10 @@ hipError_t sort_order_device(const double *d_x_layout, const uint32_t *d_perm, u
     return e != hipSuccess ? e : e2;
 }
 
+// loads this translation unit's code object (HIP loads modules on first use); see gfs_warmup
+hipError_t warm_module_index() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&step_len_kernel));
+}
+
 }  // namespace gfs

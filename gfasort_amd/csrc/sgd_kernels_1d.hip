@@ -366,4 +366,10 @@ hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool tr
     }
 }
 
+// loads this translation unit's code object (HIP loads modules on first use); see gfs_warmup
+hipError_t warm_module_1d() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&merge_prepare_kernel));
+}
+
 }  // namespace gfs

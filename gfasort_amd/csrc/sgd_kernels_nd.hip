@@ -108,4 +108,10 @@ hipError_t launch_nd_ref(int dims, const KArgs &a, bool lds_tables, bool atomic_
 #undef GFS_ND_CASE
 }
 
+// loads this translation unit's code object (HIP loads modules on first use); see gfs_warmup
+hipError_t warm_module_nd() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&sgdnd_kernel<2, true, true, false>));
+}
+
 }  // namespace gfs

@@ -188,4 +188,10 @@ hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_load
     return launch_nd_ref(dims, a, lds_tables, atomic_loads, trace, grid, block, lds, st);
 }
 
+// loads this translation unit's code object (HIP loads modules on first use); see gfs_warmup
+hipError_t warm_module_nd_team() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&sgdnd_team_kernel<2, 64, true, true, false>));
+}
+
 }  // namespace gfs
