@@ -103,8 +103,15 @@ int gfs_warmup(int device) {
     HIPCHK(gfs::warm_module_nd());
     HIPCHK(gfs::warm_module_nd_team());
     HIPCHK(gfs::warm_module_index());
+    // ... and the copy paths in both directions (the first hipMemcpy of a process sets up its staging
+    // buffers and DMA queues: ~0.13 s when it was left to the first upload)
     void *p = nullptr;
-    HIPCHK(hipMalloc(&p, 1 << 20));
+    std::vector<unsigned char> h(1 << 20, 0);
+    HIPCHK(hipMalloc(&p, 64u << 20));
+    HIPCHK(hipMemcpy(p, h.data(), h.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(p, 0, 64u << 20));
+    HIPCHK(hipMemcpy(h.data(), p, h.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipFree(p));
     return GFS_OK;
 }
@@ -435,6 +442,15 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(GFS_E_HIP, "no HIP device available (libgfasort_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(GFS_E_ARG, "bad device index");
+    const bool timing = std::getenv("GFS_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gfs_ctx_create] %-12s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    lap("validate");
     gfs_ctx *c = new (std::nothrow) gfs_ctx();
     if (!c) return fail(GFS_E_NOMEM, "out of memory");
     c->device = device;
@@ -466,6 +482,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
         for (uint64_t k = 0; k < g->n_nodes; ++k) if (c->perm[k] == 0xFFFFFFFFu) c->perm[k] = next++;
     }
 
+    lap("node layout");
     // Path records (host, P entries) and the facts the launch logic needs
     std::vector<uint4> prec(std::max<uint64_t>(g->n_paths, 1));
     for (uint64_t p = 0; p < g->n_paths; ++p) {
@@ -500,21 +517,26 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     GFS_TRY("hipMalloc perm", hipMalloc(&c->d_perm, std::max<uint64_t>(N, 1) * 4));
     GFS_TRY("hipMemcpy path_rec", hipMemcpy(c->d_path_rec, prec.data(), prec.size() * sizeof(uint4), hipMemcpyHostToDevice));
     if (N) GFS_TRY("hipMemcpy perm", hipMemcpy(c->d_perm, c->perm.data(), N * 4, hipMemcpyHostToDevice));
+    lap("alloc+small");
     if (S) {
         GFS_TRY("hipMalloc step_node", hipMalloc(&d_step_node, S * 4));
         GFS_TRY("hipMalloc step_is_rev", hipMalloc(&d_rev, S));
         GFS_TRY("hipMalloc node_len", hipMalloc(&d_node_len, std::max<uint64_t>(N, 1) * 4));
         GFS_TRY("hipMalloc path_first", hipMalloc(&d_first, (P + 1) * 8));
         GFS_TRY("hipMalloc scan", hipMalloc(&d_tmp, 2 * (S + 1) * 8));
+        lap("alloc tmp");
         GFS_TRY("hipMemcpy step_node", hipMemcpy(d_step_node, g->step_node, S * 4, hipMemcpyHostToDevice));
         GFS_TRY("hipMemcpy step_is_rev", hipMemcpy(d_rev, g->step_is_rev, S, hipMemcpyHostToDevice));
         if (N) GFS_TRY("hipMemcpy node_len", hipMemcpy(d_node_len, g->node_len, N * 4, hipMemcpyHostToDevice));
         GFS_TRY("hipMemcpy path_first", hipMemcpy(d_first, g->path_first_step, (P + 1) * 8, hipMemcpyHostToDevice));
+        lap("upload");
         GFS_TRY("build_path_index", gfs::build_path_index_device(d_step_node, d_rev, d_node_len, c->d_perm, d_first, (uint32_t)P, S,
                                                                   d_tmp, c->d_step_rec, c->d_path_len));
     }
 #undef GFS_TRY
+    lap("K3");
     free_tmp();
+    lap("free tmp");
     *out = c;
     return GFS_OK;
 }
