@@ -34,9 +34,10 @@ def main():
     ap.add_argument("--updates", type=float, default=1e7, help="term updates per iteration")
     args = ap.parse_args()
 
+    newest = lambda files: max(files, key=os.path.getmtime)      # gpurun merges runs: keep the latest
     ks = glob.glob(os.path.join(args.src, "trace", "*", "*_kernel_stats.csv"))
     if ks:
-        shutil.copy(ks[0], args.dst_prefix + "_kernel_stats.csv")
+        shutil.copy(newest(ks), args.dst_prefix + "_kernel_stats.csv")
     bj = os.path.join(args.src, "bench_trace.json")
     if os.path.exists(bj):
         shutil.copy(bj, args.dst_prefix + "_bench_under_rocprof.json")
@@ -51,7 +52,7 @@ def main():
             continue
         # (kernel, counter) -> list of (dispatch id, value); a counter may be reported once per dimension: sum
         acc = defaultdict(lambda: defaultdict(float))
-        with open(files[0]) as fh:
+        with open(newest(files)) as fh:
             for r in csv.DictReader(fh):
                 k = short(r["Kernel_Name"])
                 if "sgd" not in k:
