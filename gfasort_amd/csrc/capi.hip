@@ -571,10 +571,13 @@ int gfs_ctx_upload_positions(gfs_ctx *c, const double *host, uint64_t n) {
     if (!c->d_x) return fail(GFS_E_STATE, "context not set up");
     if (n != c->x_len) return fail(GFS_E_ARG, "positions length mismatch");
     HIPCHK(hipSetDevice(c->device));
-    const uint64_t w = c->dims ? 2 * (uint64_t)c->dims : 1;           // doubles per node
+    // device order: 1D x[slot]; nD two end planes coords[end][slot][dim] (sgd_device.h coord_ptr)
+    const uint64_t D = c->dims, N = c->n_nodes;
     std::vector<double> tmp(n);
-    for (uint64_t k = 0; k < c->n_nodes; ++k)
-        std::memcpy(&tmp[(uint64_t)c->perm[k] * w], &host[k * w], w * sizeof(double));
+    if (D == 0) for (uint64_t k = 0; k < N; ++k) tmp[c->perm[k]] = host[k];
+    else for (uint64_t k = 0; k < N; ++k)
+        for (uint64_t e = 0; e < 2; ++e)
+            std::memcpy(&tmp[(e * N + c->perm[k]) * D], &host[(k * 2 + e) * D], D * sizeof(double));
     HIPCHK(hipMemcpy(c->d_x, tmp.data(), n * 8, hipMemcpyHostToDevice));
     return GFS_OK;
 }
@@ -584,11 +587,13 @@ int gfs_ctx_download_positions(gfs_ctx *c, double *host, uint64_t n) {
     if (n != c->x_len) return fail(GFS_E_ARG, "positions length mismatch");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    const uint64_t w = c->dims ? 2 * (uint64_t)c->dims : 1;
+    const uint64_t D = c->dims, N = c->n_nodes;
     std::vector<double> tmp(n);
     HIPCHK(hipMemcpy(tmp.data(), c->d_x, n * 8, hipMemcpyDeviceToHost));
-    for (uint64_t k = 0; k < c->n_nodes; ++k)
-        std::memcpy(&host[k * w], &tmp[(uint64_t)c->perm[k] * w], w * sizeof(double));
+    if (D == 0) for (uint64_t k = 0; k < N; ++k) host[k] = tmp[c->perm[k]];
+    else for (uint64_t k = 0; k < N; ++k)
+        for (uint64_t e = 0; e < 2; ++e)
+            std::memcpy(&host[(k * 2 + e) * D], &tmp[(e * N + c->perm[k]) * D], D * sizeof(double));
     return GFS_OK;
 }
 int gfs_ctx_node_layout(const gfs_ctx *c, uint32_t *perm_out, uint64_t n) {
@@ -635,6 +640,7 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.dbg = (c->cfg.flags >> 8) & 0x7Fu;             // bit 0x40 = GFS_F_DBG_WIDE_INDEX >> 8
     if (4 * c->n_streams <= c->n_nodes) a.dbg |= 0x80u;      // team kernel: defer atomics by one trip
     a.bundle = c->bundle;
+    a.n_nodes = (uint32_t)c->n_nodes;
 }
 
 static int next_event_pair(gfs_ctx *c, std::pair<hipEvent_t, hipEvent_t> *&ev) {

@@ -90,7 +90,7 @@ struct KArgs {
     const uint4    *path_rec;
     const uint64_t *path_len;      // bp length per path (nD: length of a path's last node)
     const double   *zetas;
-    double         *x;             // 1D: x[n_nodes]; nD: coords[n_nodes*2*D] Layout order
+    double         *x;             // 1D: x[slot]; nD: END PLANES coords[end][slot][D] (see coord_ptr)
     uint64_t       *rng;           // [4][n_streams] SoA
     unsigned long long *counters;  // [slots][8]: [s][0] successful updates, [s][1] attempts (sgd_kernel_common.h)
     void           *trace;         // gfs_term[n_streams*trace_per_stream] or null
@@ -105,7 +105,7 @@ struct KArgs {
     uint32_t attempt_factor, trace_per_stream;
     uint32_t space, space_max, space_q;
     uint32_t dbg;                  // diagnostic ablation bits (GFS_F_DBG_* >> 8), 0 in production
-    uint32_t bundle, _pad2;        // lanes per sampling bundle (1 = reference streams)
+    uint32_t bundle, n_nodes;      // lanes per sampling bundle (1 = reference streams); node count (nD planes)
     IterConsts it;
 };
 
@@ -116,6 +116,15 @@ __device__ __forceinline__ uint64_t sample_step(const KArgs &a, Rng &rng) {
     return rng.uniform64(a.n_steps, a.steps_thresh);
 }
 __device__ __forceinline__ uint64_t path_first(const uint4 &pr) { return ((uint64_t)pr.w << 32) | pr.x; }
+
+// nD coordinates on the device: two END PLANES, coords[end][slot][dim].  (The ABI and Layout.coords,
+// layout.rs:14, are [node][end][dim]; upload/download translate.)  A run of consecutive nodes taking the
+// same end is then 8*D*B contiguous bytes: every 64-B line it touches is fully used, and the atomics of a
+// run need half the requests of the interleaved order, where each line also holds the other end.
+template <int D>
+__device__ __forceinline__ double *coord_ptr(const KArgs &a, uint32_t slot, bool end) {
+    return a.x + ((end ? (uint64_t)a.n_nodes : 0ull) + slot) * D;
+}
 
 // zeta index rule (sgd.rs:463-469)
 __device__ __forceinline__ uint32_t space_index(const KArgs &a, uint32_t jump) {

@@ -4,7 +4,8 @@
 namespace gfs {
 
 // ------------------------------------------------------------------------------------------
-// K2: nD, D compile-time.  coords in Layout order: [node][end][dim] (src/layout.rs:14).
+// K2: nD, D compile-time.  coords in end planes [end][slot][dim] (sgd_device.h coord_ptr); the trace
+// speaks the reference's index 2*node+end (sgd.rs:1099-1103).
 // Node lengths come from the step records themselves: pos[s+1]-pos[s] inside a path,
 // path_len - pos[s] for a path's last step (identical to graph.nodes[id].sequence.len(),
 // 0 for an absent node — sgd.rs:1051-1058 — because PathIndex positions are the exclusive
@@ -51,7 +52,7 @@ __global__ void sgdnd_kernel(const KArgs a) {
             if (ra.x == 0xFFFFFFFFu || rb.x == 0xFFFFFFFFu) continue;                  // :1089-1096
             const uint64_t idx_i = (uint64_t)ra.x * 2u + (oa ? 1u : 0u);               // :1099-1103
             const uint64_t idx_j = (uint64_t)rb.x * 2u + (ob ? 1u : 0u);
-            double *ci = a.x + idx_i * D, *cj = a.x + idx_j * D;
+            double *ci = coord_ptr<D>(a, ra.x, oa), *cj = coord_ptr<D>(a, rb.x, ob);
             double deltas[D];
             double mag_sq = 0.0;
 #pragma unroll

@@ -8,11 +8,15 @@ hipError_t launch_nd_ref(int dims, const KArgs &a, bool lds_tables, bool atomic_
                          dim3 grid, dim3 block, size_t lds, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
-// K2b: nD team kernel — the pass/trip structure of K1b for path_linear_sgd_layout.  Each acting
-// lane draws its two end flips (sgd.rs:1062,1071) from its OWN stream; node lengths come from the
-// following step record as in K2.  A run of B consecutive nodes is 32*B contiguous coordinate
-// bytes for D = 2 (Layout order), so coordinate loads and atomics coalesce like the 1D positions.
-// Atomics are issued in the trip that computes them (no deferral).
+// K2b: nD team kernel — the pass/trip structure of K1b for path_linear_sgd_layout.  The two end
+// flips of a term (sgd.rs:1062,1071) are drawn ONCE PER RUN, by the leader's stream right after it
+// sampled the leader term: every lane of the run uses the same pair.  Each term's flips are still two
+// fair independent bits; what changes is, again, only the correlation between the concurrent terms of
+// a run.  With the coordinates in end planes (coord_ptr) a run on one strand then reads and updates
+// 8*D*B CONTIGUOUS bytes per side: half the atomic requests and half the coordinate lines of
+// per-lane flips (measured: 1.08 -> 0.55 requests per update for D = 2, the atomic unit being what
+// binds this kernel).  Node lengths come from the following step record as in K2.  Atomics are
+// issued in the trip that computes them (no deferral).
 // ------------------------------------------------------------------------------------------
 template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __global__ void sgdnd_team_kernel(const KArgs a) {
@@ -40,8 +44,10 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
     while (wave_done < wave_quota && passes < max_passes) {
         ++passes;
         const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
+        const uint32_t lflips = rng.flip() | (rng.flip() << 1);            // the run's end flips: bit 0 = a, bit 1 = b
         uint64_t sa = 0, sb = 0;
         uint64_t first = bcast_first<B>(L, q); uint32_t cnt = bcast<B>(L.cnt, q);
+        uint32_t flips = bcast<B>(lflips, q);
         bool valid = expand_run<B>(bcast<B>(L.ok, q), first, cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, sa, sb);
         uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, na = ra, nb = ra;
         if (valid) {
@@ -50,11 +56,11 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
         }
 #pragma unroll 2
         for (int t = 0; t < B; ++t) {
-            uint64_t sa_n = 0, sb_n = 0, first_n = 0; uint32_t cnt_n = 0; bool valid_n = false;
+            uint64_t sa_n = 0, sb_n = 0, first_n = 0; uint32_t cnt_n = 0, flips_n = 0; bool valid_n = false;
             uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = ra_n, na_n = ra_n, nb_n = ra_n;
             if (t + 1 < B) {
                 const int ll = (t + 1) * RUNS + q;
-                first_n = bcast_first<B>(L, ll); cnt_n = bcast<B>(L.cnt, ll);
+                first_n = bcast_first<B>(L, ll); cnt_n = bcast<B>(L.cnt, ll); flips_n = bcast<B>(lflips, ll);
                 valid_n = expand_run<B>(bcast<B>(L.ok, ll), first_n, cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa_n, sb_n);
                 if (valid_n) {
                     ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n];
@@ -65,6 +71,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
             ++att;
             double term_dist = 0.0;
             uint64_t idx_i = 0, idx_j = 0;
+            bool oa = false, ob = false;
             if (valid) {
                 const uint64_t last_step = first + cnt - 1u;
                 const uint64_t plen = a.path_len[ra.y & 0x7FFFFFFFu];
@@ -74,9 +81,9 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                 double pos_a = (double)pa, pos_b = (double)pb;                         // sgd.rs:1047-1048
                 const double len_i = (double)(ea - pa), len_j = (double)(eb - pb);     // :1051-1058
                 const bool rev_i = (ra.y >> 31) != 0, rev_j = (rb.y >> 31) != 0;
-                bool oa = rng.flip() == 1u;                                            // :1062
+                oa = (flips & 1u) != 0u;                                               // :1062
                 if (oa) { pos_a += len_i; oa = !rev_i; } else { oa = rev_i; }
-                bool ob = rng.flip() == 1u;                                            // :1071
+                ob = (flips & 2u) != 0u;                                               // :1071
                 if (ob) { pos_b += len_j; ob = !rev_j; } else { ob = rev_j; }
                 term_dist = fabs(pos_a - pos_b);                                       // :1080
                 valid = term_dist != 0.0 && ra.x != 0xFFFFFFFFu && rb.x != 0xFFFFFFFFu;   // :1081, :1089-1096
@@ -96,7 +103,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
             for (int d = 0; d < D; ++d) upd_r[d] = 0.0;
             if (valid) {
                 double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                   // :1085-1086
-                double *ci = a.x + idx_i * D, *cj = a.x + idx_j * D;
+                double *ci = coord_ptr<D>(a, ra.x, oa), *cj = coord_ptr<D>(a, rb.x, ob);
                 double deltas[D];
                 double mag_sq = 0.0;
 #pragma unroll
@@ -131,10 +138,10 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                 }
             }
             if (D >= 2) {
-                // The D coordinates of an end are adjacent (8*D bytes).  Re-deal the 64 lanes' adds so that
-                // a group of P = 2 (D=2) or 4 (D=3) adjacent lanes of one instruction carries the D
-                // coordinates of the SAME end: the hardware merges them (and the neighbouring nodes of the
-                // run) into one 64-B request, which cuts the fabric atomics of the layout kernel by D.
+                // The D coordinates of an end are adjacent (8*D bytes) and so are the same ends of neighbouring
+                // nodes.  Re-deal the 64 lanes' adds so that a group of P = 2 (D=2) or 4 (D=3) adjacent lanes
+                // of one instruction carries the D coordinates of the SAME end: one instruction then covers
+                // 64/P neighbouring nodes = 512 (384 for D=3) contiguous bytes = 8-9 (6-7) requests.
                 // Wave-uniform control flow: all lanes take part in the shuffles.
                 constexpr int P = D <= 2 ? 2 : 4;
                 const int d = lane & (P - 1);
@@ -154,7 +161,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                 }
             }
             if (wave_done >= wave_quota) break;
-            ra = ra_n; rb = rb_n; na = na_n; nb = nb_n; sa = sa_n; sb = sb_n; valid = valid_n; first = first_n; cnt = cnt_n;
+            ra = ra_n; rb = rb_n; na = na_n; nb = nb_n; sa = sa_n; sb = sb_n; valid = valid_n; first = first_n; cnt = cnt_n; flips = flips_n;
         }
     }
     a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;

@@ -573,8 +573,9 @@ int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas
  * pass/trip structure and wave-level quota of sgd1d_team_kernel) so that its random-number
  * consumption and the terms it emits can be checked bit for bit.  Every stream samples leader
  * terms exactly like a reference worker (sgd.rs:444-497); a leader is expanded into a run of B
- * lanes taking consecutive steps with the leader's signed jump.  Updates of one trip are
- * applied here in lane order; the GPU applies them concurrently (and one trip late).
+ * lanes taking consecutive steps with the leader's signed jump (nD: and the leader's two end
+ * flips).  Updates of one trip are applied here in lane order; the GPU applies them concurrently
+ * (and one trip late).
  * ---------------------------------------------------------------------------------------- */
 int gfo_state_set_bundle(gfo_state *s, uint64_t bundle) {
     if (!s) return -1;
@@ -677,10 +678,17 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
             s->lead_left = (uint8_t *)calloc(T / 64, 1); s->lead_cool = (uint8_t *)calloc(T / 64, 1);
         }
         leader_t *L = s->lead + wave_first;
+        int lead_fa[64] = {0}, lead_fb[64] = {0};
         while (wave_done < wave_quota && passes < max_passes) {
             if (!carry || s->lead_left[w] == 0 || s->lead_cool[w] != (uint8_t)it.cooling) {
                 passes++;
-                for (int l = 0; l < 64; l++) L[l] = sample_leader(s, &it, s->rng + 4 * (wave_first + l));
+                for (int l = 0; l < 64; l++) {
+                    L[l] = sample_leader(s, &it, s->rng + 4 * (wave_first + l));
+                    if (s->D) {                                        /* nD: the run's two end flips, drawn by the leader's stream */
+                        lead_fa[l] = (int)flip(s->rng + 4 * (wave_first + l));
+                        lead_fb[l] = (int)flip(s->rng + 4 * (wave_first + l));
+                    }
+                }
                 s->lead_left[w] = (uint8_t)B; s->lead_cool[w] = (uint8_t)it.cooling;
             }
             for (uint64_t t = B - s->lead_left[w]; t < B && wave_done < wave_quota; t++) {
@@ -711,10 +719,10 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                         }
                         sa[l] = ld->first + ra; sb[l] = ld->first + rb;
                         if (s->D) {
-                            /* nD: the lane draws its two end flips from its OWN stream before the
-                             * term_dist test (sgd.rs:1062,1071,1080); probe the term without applying it */
-                            flips_a[l] = (int)flip(s->rng + 4 * (wave_first + l));
-                            flips_b[l] = (int)flip(s->rng + 4 * (wave_first + l));
+                            /* nD: every lane of a run uses the end flips its leader drew (sgd.rs:1062,1071);
+                             * probe the term without applying it (:1080) */
+                            flips_a[l] = lead_fa[t * RUNS + qq];
+                            flips_b[l] = lead_fb[t * RUNS + qq];
                             if (!nd_term_ok(pi, sa[l], sb[l], flips_a[l], flips_b[l])) continue;
                         } else {
                             double td = fabs((double)pi->rec[sa[l]].pos - (double)pi->rec[sb[l]].pos);

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--updates", type=float, default=1e7, help="term updates per iteration")
+    ap.add_argument("--no-traffic", action="store_true", help="do not rewrite profiles/traffic_latest.json")
     args = ap.parse_args()
 
     newest = lambda files: max(files, key=os.path.getmtime)      # gpurun merges runs: keep the latest
@@ -73,11 +74,11 @@ def main():
     with open(args.dst_prefix + "_pmc_summary.csv", "w") as fh:
         fh.write("kernel,pass,counter,dispatches,mean_per_launch,min,max,mean_per_sgd_iteration\n")
         for r in rows:
-            fh.write("%s,%s,%s,%d,%.6g,%.6g,%.6g,%.6g\n" % r)
+            fh.write("\"%s\",%s,%s,%d,%.6g,%.6g,%.6g,%.6g\n" % r)
 
     # traffic of the dominant (team) kernel
     team = [k for (k, c) in per_iter if "team" in k and c == "FETCH_SIZE"]
-    if team:
+    if team and not args.no_traffic:
         k = sorted(team, key=lambda s: "fused" not in s)[0]
         fetch_kb = per_iter[(k, "FETCH_SIZE")]
         write_kb = per_iter.get((k, "WRITE_SIZE"), float("nan"))
