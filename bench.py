@@ -102,6 +102,32 @@ def reference_streams_leg(g, p, device_index, args, steps=60):
             "avg_launch_ms": kms, "roofline_frac": (upd / steps) * ALGO_BYTES_1D / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def layout_leg(g, device_index, args, dims=2):
+    """BASELINE configs[3]: the same graph, -p L --dimensions 2 (31 iterations of 1e8 updates), resident in HBM."""
+    import torch
+    from gfasort_amd import hip, params as P, sgd as S
+    p = P.LayoutSGDParams.from_graph(g, dims, 1)
+    ctx = hip.Context(g, device=device_index)
+    ctx.setup_nd(p, hip.make_config(n_streams=args.streams, flags=args.flags | hip.F_BUNDLE(args.bundle), block_size=args.block))
+    ctx.upload(S.default_layout_init(g, dims, p.seed).ravel())
+    ctx.run_iteration(0)
+    ctx.synchronize()
+    s0 = ctx.stats()
+    t0 = time.perf_counter()
+    ctx.run_range(list(range(1, int(p.iter_max) + 1)))
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = ctx.stats()
+    ctx.close()
+    upd = s1.term_updates - s0.term_updates
+    launches = max(int(s1.launches - s0.launches), 1)
+    kms = (s1.kernel_ms - s0.kernel_ms) / launches
+    algo = 40 + 32 * dims                                  # SURVEY 8d: 2 records x 16 B + 2 ends x D x (8 read + 8 write) + ...
+    return {"value": upd / dt, "unit": "term-updates/s", "dimensions": dims, "steps": launches,
+            "sampling_bundle": int(s1.bundle), "avg_launch_ms": kms, "algorithmic_bytes_per_update": algo,
+            "roofline_frac": (upd / launches) * algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def wall_clock_leg(g):
     """The other half of BASELINE's metric: wall-clock of the whole `-p Y --iter-max 200` run,
     GFA text in -> sorted GFA text out, through the C++ CLI (gfasort_amd/bin/gfasort_hip)."""
@@ -264,6 +290,8 @@ def main():
         }
         if world == 1 and int(st1.bundle) != 1:
             out["reference_streams"] = reference_streams_leg(g, p, local_rank, args)
+        if world == 1:
+            out["layout_2d"] = layout_leg(g, local_rank, args)
         if world == 1 and not args.no_cpu_baseline:
             out["wall_clock_pY"] = wall_clock_leg(g)
             out["cpu_baseline"] = cpu_baseline(g, p)
