@@ -117,8 +117,11 @@ class ShardedSGD:
 
     def __init__(self, graph: FlatGraph, params, rank: int, world: int, engine_factory: Callable,
                  dims: int = 0, streams_per_rank: int = 0, merge: str = "touch", dist=None,
-                 merge_every: int = 1, sharding: str = "auto"):
+                 merge_every: int = 1, sharding: str = "auto", force_merge: bool = False):
         self.rank, self.world, self.merge = rank, world, merge
+        # force_merge: run the merge (kernels + collective) even with one rank — a 1-rank RCCL group is the
+        # only way to exercise the real collective path on a one-GPU machine (tests)
+        self.merging = world > 1 or (force_merge and dist is not None)
         self.dist = dist
         self.merge_every = max(1, int(merge_every))
         counts = graph.path_step_counts()
@@ -140,18 +143,18 @@ class ShardedSGD:
         self.engine = engine_factory(local, params, dims, self.quotas[rank], rank, streams_per_rank)
         self.x_prev = None
         self._buf = None
-        if world > 1:
+        if self.merging:
             import torch
             self._torch = torch
             self.x_prev = torch.empty_like(self.engine.positions)
 
     def set_positions(self, x: np.ndarray):
         self.engine.set_positions(x)
-        if self.world > 1:
+        if self.merging:
             self.x_prev.copy_(self.engine.positions)
 
     def _merge_due(self, k: int) -> bool:
-        return self.world > 1 and ((k + 1) % self.merge_every == 0 or k == int(self.params.iter_max))
+        return self.merging and ((k + 1) % self.merge_every == 0 or k == int(self.params.iter_max))
 
     def run_iteration(self, k: int):
         self.engine.run_iteration(k)

@@ -672,3 +672,51 @@ def test_fused_range_with_repeated_and_partial_schedules():
         with pytest.raises(Exception):
             ctx.run_range([21])
         ctx.close()
+
+
+# ---- the real collective library: a ONE-rank RCCL group on the one GPU -----------------------------------------
+def _rccl_rank(port, out):
+    """Everything bench.py does for N > 1 except having peers: RCCL init on cuda:0, the f32 [delta, touched]
+    all-reduce between the two merge kernels on torch's current stream, fused launches between merges."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from gfasort_amd.distributed import ShardedSGD, hip_engine_factory
+    g = G.synth_windows(1_000_000, 64, 156_250, 2)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 60
+    r = ShardedSGD(g, p, 0, 1, hip_engine_factory(device_index=0), dims=0, dist=dist, merge_every=4, force_merge=True)
+    r.set_positions(hip.init_positions(g))
+    r.run()
+    torch.cuda.synchronize()
+    st = r.engine.stats()
+    t = torch.ones(8, device="cuda")
+    dist.all_reduce(t)
+    out.put((r.positions_numpy(), int(st.term_updates), int(st.launches), float(t.sum().item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_the_merge_path():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    pr = ctx.Process(target=_rccl_rank, args=(port, out))
+    pr.start()
+    x, upd, launches, ones = out.get(timeout=300)
+    pr.join(timeout=60)
+    assert pr.exitcode == 0 and ones == 8.0
+    g = G.synth_windows(1_000_000, 64, 156_250, 2)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 60
+    assert upd == (p.iter_max + 1) * p.min_term_updates
+    assert launches == -(-(p.iter_max + 1) // 4)            # one fused launch per merge window of 4 iterations
+    # merging with nobody is x_prev + f32(x - x_prev): the sort still comes out in exact chain order
+    assert np.isfinite(x).all() and _chain_order_ok(g, x)
