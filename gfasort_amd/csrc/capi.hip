@@ -222,7 +222,8 @@ struct gfs_ctx {
     uint32_t *d_lead = nullptr;      // 1D team kernels: the waves' partly expanded passes, [6][n_streams]
     unsigned long long *d_counters = nullptr;
     gfs_term *d_trace = nullptr; uint32_t *d_trace_cnt = nullptr;
-    gfs::IterConsts *d_its = nullptr; uint64_t its_cap = 0;   // schedule slice of a fused launch
+    gfs::IterConsts *d_its = nullptr; uint64_t its_cap = 0;   // schedule slice of a fused launch (arbitrary lists)
+    gfs::IterConsts *d_its_all = nullptr;                     // constants of iterations 0..=iter_max, resident
     uint64_t n_streams = 0, quota_total = 0;
     uint32_t block = 256;
     uint32_t bundle = 1;               // lanes per sampling bundle actually used (1 = reference streams)
@@ -247,7 +248,8 @@ static void free_sgd_state(gfs_ctx *c) {
     if (c->d_trace) (void)hipFree(c->d_trace);
     if (c->d_trace_cnt) (void)hipFree(c->d_trace_cnt);
     if (c->d_its) (void)hipFree(c->d_its);
-    c->d_its = nullptr; c->its_cap = 0;
+    if (c->d_its_all) (void)hipFree(c->d_its_all);
+    c->d_its = nullptr; c->its_cap = 0; c->d_its_all = nullptr;
     c->d_zetas = nullptr; c->d_x = nullptr; c->d_rng = nullptr; c->d_counters = nullptr;
     c->d_trace = nullptr; c->d_trace_cnt = nullptr; c->x_owned = false; c->configured = false;
 }
@@ -340,6 +342,8 @@ static int choose_bundle(gfs_ctx *c, int dims) {
     return GFS_OK;
 }
 
+static void iter_consts(const gfs_ctx *c, uint64_t k, gfs::IterConsts &it);
+
 static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs_launch_config *cfg,
                         const double *etas, const double *zetas) {
     if (!c) return fail(GFS_E_ARG, "ctx is null");
@@ -396,6 +400,13 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     }
     rc = seed_streams(c);
     if (rc) return rc;
+    if (dims == 0 && c->bundle >= 16 && c->params.iter_max < (1u << 20)) {
+        // the whole schedule's per-iteration constants, for fused launches over consecutive iterations
+        std::vector<gfs::IterConsts> all(c->params.iter_max + 1);
+        for (uint64_t k = 0; k <= c->params.iter_max; ++k) iter_consts(c, k, all[k]);
+        HIPCHK(hipMalloc(&c->d_its_all, all.size() * sizeof(gfs::IterConsts)));
+        HIPCHK(hipMemcpy(c->d_its_all, all.data(), all.size() * sizeof(gfs::IterConsts), hipMemcpyHostToDevice));
+    }
     c->configured = true;
     return GFS_OK;
 }
@@ -703,25 +714,33 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    std::vector<gfs::IterConsts> its(n);
-    for (uint64_t i = 0; i < n; ++i) iter_consts(c, ks[i], its[i]);
-    if (c->its_cap < n) {
-        if (c->d_its) HIPCHK(hipFree(c->d_its));
-        c->d_its = nullptr; c->its_cap = 0;
-        HIPCHK(hipMalloc(&c->d_its, n * sizeof(gfs::IterConsts)));
-        c->its_cap = n;
+    bool consecutive = c->d_its_all != nullptr;
+    for (uint64_t i = 1; i < n && consecutive; ++i) consecutive = ks[i] == ks[0] + i;
+    const gfs::IterConsts *d_slice = nullptr;
+    if (consecutive) {
+        d_slice = c->d_its_all + ks[0];               // resident table: nothing to upload, nothing to wait for
+    } else {
+        std::vector<gfs::IterConsts> its(n);
+        for (uint64_t i = 0; i < n; ++i) iter_consts(c, ks[i], its[i]);
+        if (c->its_cap < n) {
+            if (c->d_its) HIPCHK(hipFree(c->d_its));
+            c->d_its = nullptr; c->its_cap = 0;
+            HIPCHK(hipMalloc(&c->d_its, n * sizeof(gfs::IterConsts)));
+            c->its_cap = n;
+        }
+        HIPCHK(hipMemcpyAsync(c->d_its, its.data(), n * sizeof(gfs::IterConsts), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));             // `its` is a stack-lifetime staging buffer
+        d_slice = c->d_its;
     }
-    HIPCHK(hipMemcpyAsync(c->d_its, its.data(), n * sizeof(gfs::IterConsts), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));                 // `its` is a stack-lifetime staging buffer
     gfs::KArgs a{};
     fill_kargs(c, a);
-    a.it = its[0];
+    iter_consts(c, ks[0], a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     int rc = next_event_pair(c, ev);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev->first, st));
-    hipError_t e = gfs::launch_1d_fused(a, c->d_its, (uint32_t)n, c->lds_tables, grid, block, c->lds_bytes, st);
+    hipError_t e = gfs::launch_1d_fused(a, d_slice, (uint32_t)n, c->lds_tables, grid, block, c->lds_bytes, st);
     if (e != hipSuccess) return fail(GFS_E_HIP, std::string("fused kernel launch: ") + hipGetErrorString(e));
     HIPCHK(hipEventRecord(ev->second, st));
     c->iterations += n;
