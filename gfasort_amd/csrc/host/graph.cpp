@@ -23,7 +23,7 @@ std::atomic<size_t> g_io_threads{0};
 
 // items 0..n-1 handed out one at a time; the exception of the LOWEST failing item is rethrown, which is
 // the one a sequential pass would have hit first
-void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+void parallel_for_impl(size_t n, const std::function<void(size_t)> &fn) {
     size_t nt = std::min(io_threads(), n);
     if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
     std::atomic<size_t> next{0};
@@ -54,6 +54,7 @@ std::vector<StepChunk> step_chunks(const std::vector<BiPath> &paths, size_t chun
 }
 }  // namespace
 
+void parallel_for(size_t n, const std::function<void(size_t)> &fn) { parallel_for_impl(n, fn); }
 void set_io_threads(size_t n) { g_io_threads = n; }
 size_t io_threads() {
     size_t n = g_io_threads;

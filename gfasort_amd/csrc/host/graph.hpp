@@ -8,6 +8,7 @@
 // plus the flattened SoA mirror (gfs_graph_view) that the HIP library consumes.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <optional>
 #include <ostream>
 #include <string>
@@ -159,6 +160,8 @@ struct BidirectedGraph {
 // write): 0 = auto (the CPUs this process may run on, at most 16).  Results do not depend on it.
 void set_io_threads(size_t n);
 size_t io_threads();
+// fn(0..n-1) on the host threads; the exception of the lowest failing item is rethrown
+void parallel_for(size_t n, const std::function<void(size_t)> &fn);
 
 // Whole file into a string (one read of the file's size).  Throws std::runtime_error(strerror).
 std::string read_file(const std::string &path);

@@ -118,11 +118,33 @@ void Layout::write_tsv(std::ostream &out) const {
     for (size_t d = 0; d < dimensions; ++d) out << "\t" << dim_name(d) << "+";
     for (size_t d = 0; d < dimensions; ++d) out << "\t" << dim_name(d) << "-";
     out << "\n";
-    for (size_t node = 0; node < num_nodes; ++node) {
-        out << node;
-        for (size_t end = 0; end < 2; ++end)
-            for (size_t d = 0; d < dimensions; ++d) out << "\t" << rust_display_f64(get(node, end, d));
-        out << "\n";
+    // rows formatted in blocks by the host threads, a window of blocks at a time, written in order
+    const size_t BLOCK = 1 << 14, nblocks = (num_nodes + BLOCK - 1) / BLOCK;
+    const size_t window = std::max<size_t>(io_threads() * 4, 1);
+    std::vector<std::string> piece(std::min(window, std::max<size_t>(nblocks, 1)));
+    for (size_t base = 0; base < nblocks; base += window) {
+        const size_t n = std::min(window, nblocks - base);
+        parallel_for(n, [&](size_t i) {
+            std::string &o = piece[i];
+            o.clear();
+            o.reserve(BLOCK * (8 + 2 * dimensions * 20));
+            char buf[512];
+            const size_t lo = (base + i) * BLOCK, hi = std::min(num_nodes, lo + BLOCK);
+            for (size_t node = lo; node < hi; ++node) {
+                auto r = std::to_chars(buf, buf + sizeof buf, node);
+                o.append(buf, r.ptr);
+                for (size_t end = 0; end < 2; ++end)
+                    for (size_t d = 0; d < dimensions; ++d) {
+                        o.push_back('\t');
+                        const double v = get(node, end, d);
+                        if (v != v || std::isinf(v)) { o += rust_display_f64(v); continue; }
+                        auto rv = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+                        o.append(buf, rv.ptr);
+                    }
+                o.push_back('\n');
+            }
+        });
+        for (size_t i = 0; i < n; ++i) out.write(piece[i].data(), (std::streamsize)piece[i].size());
     }
 }
 
@@ -201,15 +223,17 @@ std::vector<double> default_layout_init(const FlatGraph &f, size_t D, uint64_t s
     const size_t N = f.node_len.size(), n = N * 2 * D;
     std::vector<double> c(n, 0.0);
     if (D > 1) {
-        std::vector<uint64_t> r(2 * n);
-        uint64_t s = seed;
-        for (auto &v : r) v = splitmix64(s);
+        // r[k] = k-th output of SplitMix64(seed): the state advances by a constant, so any k is addressable
+        auto draw = [seed](uint64_t k) { uint64_t st = seed + k * 0x9E3779B97F4A7C15ull; return splitmix64(st); };
         const double scale = std::sqrt(2.0 * (double)N);             // sgd.rs:836
-        for (size_t k = 0; k < n; ++k) {
-            double u1 = ((double)(r[k] >> 11) + 1.0) / 9007199254740993.0;
-            double u2 = (double)(r[n + k] >> 11) / 9007199254740992.0;
-            c[k] = std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2) * scale;
-        }
+        const size_t BLOCK = 1 << 16;
+        parallel_for((n + BLOCK - 1) / BLOCK, [&](size_t b) {
+            for (size_t k = b * BLOCK; k < std::min(n, (b + 1) * BLOCK); ++k) {
+                double u1 = ((double)(draw(k) >> 11) + 1.0) / 9007199254740993.0;
+                double u2 = (double)(draw(n + k) >> 11) / 9007199254740992.0;
+                c[k] = std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2) * scale;
+            }
+        });
     }
     gfs_graph_view v = f.view();
     std::vector<double> c0(n);
