@@ -26,6 +26,8 @@ hipError_t warm_module_1d();
 hipError_t warm_module_nd();
 hipError_t warm_module_nd_team();
 hipError_t warm_module_index();
+hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_steps, uint64_t n_nodes, uint32_t *d_perm,
+                                     int *bad_out);
 hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
                                    const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
                                    uint64_t n_steps, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len);
@@ -446,9 +448,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
         return fail(GFS_E_ARG, "path_first_step must start at 0 and end at n_steps");
     for (uint64_t p = 0; p < g->n_paths; ++p)
         if (g->path_first_step[p + 1] < g->path_first_step[p]) return fail(GFS_E_ARG, "path_first_step not monotone");
-    for (uint64_t s = 0; s < g->n_steps; ++s)
-        if (g->step_node[s] != GFS_NO_NODE && g->step_node[s] >= g->n_nodes)
-            return fail(GFS_E_ARG, "step_node out of range");
+    // (step_node's range is checked on the device, in the pass that derives the node layout)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(GFS_E_HIP, "no HIP device available (libgfasort_hip has no CPU fallback)");
@@ -473,8 +473,8 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     c->cu_count = prop.multiProcessorCount;
 
     // Internal node layout.  The position vector is stored in FIRST-VISIT PATH ORDER (nodes in the
-    // order the paths first step on them, unvisited nodes last) unless the caller supplies a
-    // layout: consecutive steps of a path then touch neighbouring position words whatever the
+    // order the paths first step on them, unvisited nodes last; derived on the device, index_kernels.hip)
+    // unless the caller supplies a layout: consecutive steps of a path then touch neighbouring position words whatever the
     // order of the input's S lines was, which is what lets a run's loads and atomics coalesce
     // (C3: 47 G updates/s in path order, 10 G/s with randomly ordered nodes).
     c->perm.assign(g->n_nodes, 0xFFFFFFFFu);
@@ -484,16 +484,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
             if (node_perm[k] >= g->n_nodes || seen[node_perm[k]]) { delete c; return fail(GFS_E_ARG, "node_perm is not a permutation"); }
             seen[node_perm[k]] = 1; c->perm[k] = node_perm[k];
         }
-    } else {
-        uint32_t next = 0;
-        for (uint64_t s = 0; s < g->n_steps; ++s) {
-            uint32_t n = g->step_node[s];
-            if (n != GFS_NO_NODE && c->perm[n] == 0xFFFFFFFFu) c->perm[n] = next++;
-        }
-        for (uint64_t k = 0; k < g->n_nodes; ++k) if (c->perm[k] == 0xFFFFFFFFu) c->perm[k] = next++;
     }
-
-    lap("node layout");
     // Path records (host, P entries) and the facts the launch logic needs
     std::vector<uint4> prec(std::max<uint64_t>(g->n_paths, 1));
     for (uint64_t p = 0; p < g->n_paths; ++p) {
@@ -527,16 +518,31 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     GFS_TRY("hipMalloc path_len", hipMalloc(&c->d_path_len, std::max<uint64_t>(P, 1) * 8));
     GFS_TRY("hipMalloc perm", hipMalloc(&c->d_perm, std::max<uint64_t>(N, 1) * 4));
     GFS_TRY("hipMemcpy path_rec", hipMemcpy(c->d_path_rec, prec.data(), prec.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    if (N) GFS_TRY("hipMemcpy perm", hipMemcpy(c->d_perm, c->perm.data(), N * 4, hipMemcpyHostToDevice));
-    lap("alloc+small");
     if (S) {
         GFS_TRY("hipMalloc step_node", hipMalloc(&d_step_node, S * 4));
+        GFS_TRY("hipMemcpy step_node", hipMemcpy(d_step_node, g->step_node, S * 4, hipMemcpyHostToDevice));
+    }
+    lap("step upload");
+    {
+        // range check of step_node, and (unless the caller brought a layout) the first-visit order
+        int bad = 0;
+        uint32_t *d_scratch_perm = nullptr;
+        uint32_t *target = c->d_perm;
+        if (node_perm && N) { GFS_TRY("hipMalloc scratch", hipMalloc(&d_scratch_perm, N * 4)); target = d_scratch_perm; }
+        e = gfs::first_visit_layout_device(d_step_node, S, N, target, &bad);
+        if (d_scratch_perm) (void)hipFree(d_scratch_perm);
+        if (e != hipSuccess) { free_tmp(); return bail("first_visit_layout", e); }
+        if (bad) { free_tmp(); gfs_ctx_destroy(c); return fail(GFS_E_ARG, "step_node out of range"); }
+        if (N && node_perm) { GFS_TRY("hipMemcpy perm", hipMemcpy(c->d_perm, c->perm.data(), N * 4, hipMemcpyHostToDevice)); }
+        if (N && !node_perm) { GFS_TRY("hipMemcpy perm", hipMemcpy(c->perm.data(), c->d_perm, N * 4, hipMemcpyDeviceToHost)); }
+    }
+    lap("node layout");
+    if (S) {
         GFS_TRY("hipMalloc step_is_rev", hipMalloc(&d_rev, S));
         GFS_TRY("hipMalloc node_len", hipMalloc(&d_node_len, std::max<uint64_t>(N, 1) * 4));
         GFS_TRY("hipMalloc path_first", hipMalloc(&d_first, (P + 1) * 8));
         GFS_TRY("hipMalloc scan", hipMalloc(&d_tmp, 2 * (S + 1) * 8));
         lap("alloc tmp");
-        GFS_TRY("hipMemcpy step_node", hipMemcpy(d_step_node, g->step_node, S * 4, hipMemcpyHostToDevice));
         GFS_TRY("hipMemcpy step_is_rev", hipMemcpy(d_rev, g->step_is_rev, S, hipMemcpyHostToDevice));
         if (N) GFS_TRY("hipMemcpy node_len", hipMemcpy(d_node_len, g->node_len, N * 4, hipMemcpyHostToDevice));
         GFS_TRY("hipMemcpy path_first", hipMemcpy(d_first, g->path_first_step, (P + 1) * 8, hipMemcpyHostToDevice));

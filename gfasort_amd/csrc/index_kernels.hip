@@ -72,6 +72,68 @@ hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d
     return e != hipSuccess ? e : e2;
 }
 
+// ---- internal node layout (first-visit path order) --------------------------------------------------
+// perm[n] = number of distinct nodes the paths step on before they first step on n; nodes no path visits
+// follow in index order.  (What a scan over the steps with a counter gives; done here as min-reduction +
+// stable sort so that a 4.5e9-step graph takes 0.3 s instead of 25 s on one host core.)  The same pass
+// validates step_node (dense index < n_nodes, or NO_NODE).
+__global__ void first_visit_kernel(const uint32_t *step_node, uint64_t n_steps, uint64_t n_nodes,
+                                   unsigned long long *first, int *bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_steps; s += stride) {
+        const uint32_t n = step_node[s];
+        if (n == 0xFFFFFFFFu) continue;
+        if (n >= n_nodes) { *bad = 1; continue; }
+        if (first[n] > s) atomicMin(&first[n], (unsigned long long)s);      // the plain read only skips work
+    }
+}
+__global__ void iota_kernel(uint32_t *v, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) v[k] = (uint32_t)k;
+}
+__global__ void scatter_rank_kernel(const uint32_t *sorted_node, uint32_t *perm, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) perm[sorted_node[r]] = (uint32_t)r;
+}
+
+// d_perm: n_nodes u32 (device).  *bad_out = 1 when a step names a node >= n_nodes.  Synchronous.
+hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_steps, uint64_t n_nodes, uint32_t *d_perm,
+                                     int *bad_out) {
+    *bad_out = 0;
+    if (n_nodes == 0) return hipSuccess;
+    unsigned long long *d_first = nullptr, *d_first_sorted = nullptr;
+    uint32_t *d_ids = nullptr, *d_ids_sorted = nullptr;
+    int *d_bad = nullptr;
+    void *d_tmp = nullptr;
+    hipError_t e = hipSuccess;
+    auto done = [&](hipError_t err) {
+        (void)hipFree(d_first); (void)hipFree(d_first_sorted); (void)hipFree(d_ids); (void)hipFree(d_ids_sorted);
+        (void)hipFree(d_bad); (void)hipFree(d_tmp);
+        return err;
+    };
+    if ((e = hipMalloc(&d_first, n_nodes * 8)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_first_sorted, n_nodes * 8)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_ids, n_nodes * 4)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_ids_sorted, n_nodes * 4)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_bad, sizeof(int))) != hipSuccess) return done(e);
+    if ((e = hipMemset(d_first, 0xFF, n_nodes * 8)) != hipSuccess) return done(e);
+    if ((e = hipMemset(d_bad, 0, sizeof(int))) != hipSuccess) return done(e);
+    if (n_steps) hipLaunchKernelGGL(first_visit_kernel, dim3(4096), dim3(256), 0, 0, d_step_node, n_steps, n_nodes, d_first, d_bad);
+    hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, 0, d_ids, n_nodes);
+    size_t tmp_bytes = 0;
+    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t *)d_first, (uint64_t *)d_first_sorted, d_ids, d_ids_sorted,
+                                  (size_t)n_nodes, 0, 64, 0);
+    if (e != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8)) != hipSuccess) return done(e);
+    e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (uint64_t *)d_first, (uint64_t *)d_first_sorted, d_ids, d_ids_sorted,
+                                  (size_t)n_nodes, 0, 64, 0);                 // stable: unvisited nodes stay in index order
+    if (e != hipSuccess) return done(e);
+    hipLaunchKernelGGL(scatter_rank_kernel, dim3(1024), dim3(256), 0, 0, d_ids_sorted, d_perm, n_nodes);
+    if ((e = hipGetLastError()) != hipSuccess) return done(e);
+    if ((e = hipMemcpy(bad_out, d_bad, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return done(e);
+    return done(hipDeviceSynchronize());
+}
+
 // ---- K6 ------------------------------------------------------------------------------------------
 // Order-preserving u64 image of an f64: -0.0 is folded onto +0.0 (partial_cmp calls them equal, so the
 // tie must be broken by index, sgd.rs:666); NaNs (never produced by a finite run) sort after all numbers.

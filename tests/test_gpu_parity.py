@@ -720,3 +720,26 @@ def test_one_rank_rccl_group_runs_the_merge_path():
     assert launches == -(-(p.iter_max + 1) // 4)            # one fused launch per merge window of 4 iterations
     # merging with nobody is x_prev + f32(x - x_prev): the sort still comes out in exact chain order
     assert np.isfinite(x).all() and _chain_order_ok(g, x)
+
+
+def test_device_node_layout_with_unvisited_nodes_absent_steps_and_bad_indices():
+    """The first-visit layout and the range check of step_node run on the device (index_kernels.hip)."""
+    from gfasort_amd.distributed import path_order_layout
+    rng = np.random.default_rng(11)
+    n, S = 5000, 40000
+    step_node = rng.integers(0, n // 2, S).astype(np.uint32) * 2             # odd nodes are never visited
+    step_node[rng.integers(0, S, 200)] = 0xFFFFFFFF                          # steps on absent nodes
+    g = G.FlatGraph(node_len=rng.integers(1, 9, n).astype(np.uint32), step_node=step_node,
+                    step_is_rev=np.zeros(S, dtype=np.uint8), path_first_step=np.array([0, S // 3, S // 3, S], dtype=np.uint64),
+                    node_ids=np.arange(1, n + 1, dtype=np.uint64), path_names=["a", "b", "c"])
+    ctx = hip.Context(g)
+    perm = ctx.node_layout()
+    assert np.array_equal(perm, path_order_layout(g))
+    unvisited = np.setdiff1d(np.arange(n), step_node[step_node != 0xFFFFFFFF])
+    assert np.all(np.diff(perm[unvisited]) == 1) and perm[unvisited][-1] == n - 1      # last, in index order
+    ctx.close()
+    bad = step_node.copy(); bad[12345] = n
+    g.step_node = bad
+    with pytest.raises(hip.GfsError) as ei:
+        hip.Context(g)
+    assert ei.value.code == -1 and "out of range" in str(ei.value)
