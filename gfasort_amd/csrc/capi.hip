@@ -26,6 +26,8 @@ hipError_t warm_module_1d();
 hipError_t warm_module_nd();
 hipError_t warm_module_nd_team();
 hipError_t warm_module_index();
+hipError_t reorder_positions_device(const double *d_src, double *d_dst, const uint32_t *d_perm, uint64_t N, uint32_t D,
+                                    int to_device, hipStream_t st);
 hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_steps, uint64_t n_nodes, uint32_t *d_perm,
                                      int *bad_out);
 hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
@@ -588,14 +590,14 @@ int gfs_ctx_upload_positions(gfs_ctx *c, const double *host, uint64_t n) {
     if (!c->d_x) return fail(GFS_E_STATE, "context not set up");
     if (n != c->x_len) return fail(GFS_E_ARG, "positions length mismatch");
     HIPCHK(hipSetDevice(c->device));
-    // device order: 1D x[slot]; nD two end planes coords[end][slot][dim] (sgd_device.h coord_ptr)
-    const uint64_t D = c->dims, N = c->n_nodes;
-    std::vector<double> tmp(n);
-    if (D == 0) for (uint64_t k = 0; k < N; ++k) tmp[c->perm[k]] = host[k];
-    else for (uint64_t k = 0; k < N; ++k)
-        for (uint64_t e = 0; e < 2; ++e)
-            std::memcpy(&tmp[(e * N + c->perm[k]) * D], &host[(k * 2 + e) * D], D * sizeof(double));
-    HIPCHK(hipMemcpy(c->d_x, tmp.data(), n * 8, hipMemcpyHostToDevice));
+    // device order: 1D x[slot]; nD two end planes coords[end][slot][dim] — reordered on the device
+    double *d_stage = nullptr;
+    HIPCHK(hipMalloc(&d_stage, n * 8));
+    hipError_t e = hipMemcpy(d_stage, host, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = gfs::reorder_positions_device(d_stage, c->d_x, c->d_perm, c->n_nodes, (uint32_t)c->dims, 1, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_stage);
+    if (e != hipSuccess) return fail(GFS_E_HIP, std::string("upload_positions: ") + hipGetErrorString(e));
     return GFS_OK;
 }
 int gfs_ctx_download_positions(gfs_ctx *c, double *host, uint64_t n) {
@@ -604,13 +606,12 @@ int gfs_ctx_download_positions(gfs_ctx *c, double *host, uint64_t n) {
     if (n != c->x_len) return fail(GFS_E_ARG, "positions length mismatch");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    const uint64_t D = c->dims, N = c->n_nodes;
-    std::vector<double> tmp(n);
-    HIPCHK(hipMemcpy(tmp.data(), c->d_x, n * 8, hipMemcpyDeviceToHost));
-    if (D == 0) for (uint64_t k = 0; k < N; ++k) host[k] = tmp[c->perm[k]];
-    else for (uint64_t k = 0; k < N; ++k)
-        for (uint64_t e = 0; e < 2; ++e)
-            std::memcpy(&host[(k * 2 + e) * D], &tmp[(e * N + c->perm[k]) * D], D * sizeof(double));
+    double *d_stage = nullptr;
+    HIPCHK(hipMalloc(&d_stage, n * 8));
+    hipError_t e = gfs::reorder_positions_device(c->d_x, d_stage, c->d_perm, c->n_nodes, (uint32_t)c->dims, 0, 0);
+    if (e == hipSuccess) e = hipMemcpy(host, d_stage, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_stage);
+    if (e != hipSuccess) return fail(GFS_E_HIP, std::string("download_positions: ") + hipGetErrorString(e));
     return GFS_OK;
 }
 int gfs_ctx_node_layout(const gfs_ctx *c, uint32_t *perm_out, uint64_t n) {

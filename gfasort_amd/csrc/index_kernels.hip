@@ -134,6 +134,27 @@ hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_ste
     return done(hipDeviceSynchronize());
 }
 
+// ---- ABI order <-> device order of positions / coordinates ------------------------------------------------
+// ABI: x[k] (1D, D = 0) or coords[(k*2 + end)*D + dim] by dense index k; device: x[perm[k]] or the end planes
+// coords[(end*N + perm[k])*D + dim] (sgd_device.h coord_ptr).  to_device = 1: abi -> dev, else dev -> abi.
+__global__ void reorder_positions_kernel(const double *src, double *dst, const uint32_t *perm, uint64_t N, uint32_t D, int to_device) {
+    const uint64_t W = D ? 2ull * D : 1ull, total = N * W;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint64_t k = t / W, r = t - k * W;                  // t walks the ABI order
+        uint64_t dev;
+        if (D == 0) dev = perm[k];
+        else { const uint64_t end = r / D, d = r - end * D; dev = (end * N + perm[k]) * D + d; }
+        if (to_device) dst[dev] = src[t]; else dst[t] = src[dev];
+    }
+}
+hipError_t reorder_positions_device(const double *d_src, double *d_dst, const uint32_t *d_perm, uint64_t N, uint32_t D,
+                                    int to_device, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(reorder_positions_kernel, dim3(2048), dim3(256), 0, st, d_src, d_dst, d_perm, N, D, to_device);
+    return hipGetLastError();
+}
+
 // ---- K6 ------------------------------------------------------------------------------------------
 // Order-preserving u64 image of an f64: -0.0 is folded onto +0.0 (partial_cmp calls them equal, so the
 // tie must be broken by index, sgd.rs:666); NaNs (never produced by a finite run) sort after all numbers.
