@@ -305,10 +305,11 @@ static int upload_zeta_table(gfs_ctx *c, const gfs_sgd_params *p, const double *
 
 // Streams per launch when the caller leaves it to the library.
 static uint64_t auto_stream_count(const gfs_ctx *c) {
-    // 512 lanes per CU (2 waves per SIMD) measured best on MI355X for the team kernel and within
-    // 5 % of best for reference streams (profiles/r01/sweep_streams*.log): more resident waves only
-    // lengthen the queues in front of the memory-side atomic units.
-    const uint64_t chip = (uint64_t)c->cu_count * 512;
+    // 768 lanes per CU (3 waves per SIMD): the measured optimum on MI355X for the team kernels, fused or
+    // one launch per iteration, 1D and nD (profiles/r01/sweep_streams_final.log; reference streams are flat
+    // within 5 % from 512 up).  Each wave is a serial chain of memory round trips, so more chains raise
+    // throughput until the memory-side atomic units saturate; past ~1024 lanes per CU nothing is gained.
+    const uint64_t chip = (uint64_t)c->cu_count * 768;
     // keep >= 8 updates per stream per batch on small graphs
     const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
     // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight
