@@ -330,13 +330,17 @@ static int choose_bundle(gfs_ctx *c, int dims) {
     if (b > 1 && dims != 0 && (dims > 3 || b == 4))
         return fail(GFS_E_UNSUPPORTED, "bundled layout kernels exist for 1..3 dimensions and bundles of 8..64");
     if (b == 0) {
-        // auto: the widest bundle that still leaves >= 65536 independent leader draws per iteration and
-        // has >= 95 % of the steps in paths of at least 4*B steps.  Small graphs run reference streams.
+        // auto: the widest bundle that still leaves >= 4096 independent leader draws per iteration and has
+        // >= 95 % of the steps in paths of at least 4*B steps, on graphs of >= 16384 nodes.  Measured at equal
+        // update counts (profiles/r01/bundle_quality_mid.log, bundle_quality_team.log): bubble graphs of 26k /
+        // 79k / 197k / 525k nodes end at stress 0.0068 / 0.0040 / 0.0030 / 0.0022 with B = 64 against 0.0069 /
+        // 0.0038 / 0.0027 / 0.0020 with reference streams, 2.4-4.4x faster; DRB1 (5k nodes) converges visibly
+        // slower with bundles (0.34 vs 0.32 after 100 iterations), so small graphs run reference streams.
         b = 1;
-        if (T % 64 == 0 && dims <= 3) {
+        if (T % 64 == 0 && dims <= 3 && c->n_nodes >= 16384) {
             for (uint32_t cand : {64u, 32u, 16u, 8u, 4u}) {
                 if (cand == 4u && dims != 0) continue;
-                if (c->quota_total / cand < 65536) continue;
+                if (c->quota_total / cand < 4096) continue;
                 uint64_t long_steps = 0;
                 for (uint32_t cnt : c->path_counts) if (cnt >= 4 * cand) long_steps += cnt;
                 if ((double)long_steps >= 0.95 * (double)c->n_steps) { b = cand; break; }

@@ -100,7 +100,7 @@ typedef struct gfs_launch_config {
  * same signed jump, so that record loads, position loads and atomics of a bundle coalesce into a
  * few 64-B requests (gfasort_amd/csrc/sgd_device.h).  n = 1: reference streams, every lane is a
  * reference worker thread.  n = 0 (default): the library picks by graph size — 1 for small
- * graphs, up to 64 when an iteration still has >= 65536 independent bundle draws.            */
+ * graphs (< 16384 nodes), else up to 64 while an iteration still has >= 4096 independent draws. */
 #define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* n in {0 = auto, 1, 4, 8, 16, 32, 64} */
 #define GFS_F_NO_FUSE       4u        /* gfs_ctx_run / gfs_ctx_run_range: one launch per iteration even where
                                          a fused persistent launch is possible                        */

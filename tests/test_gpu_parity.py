@@ -306,9 +306,12 @@ def test_auto_bundle_policy():
     g_small = load("DRB1-3123.gfa")
     rc, x, st = hip.path_linear_sgd_raw(g_small, _ygs(g_small, 2))
     assert st.bundle == 1                                            # small graph: reference streams
-    g_mid = G.synth_bubbles(20000, 16, 5)                            # 325k steps -> 4 lanes per bundle
+    g_mid = G.synth_bubbles(20000, 16, 5)                            # 26k nodes, 325k steps: 5078 leader draws at B = 64
     rc, x, st = hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2))
-    assert st.bundle == 4
+    assert st.bundle == 64
+    g_w = G.synth_windows(50_000, 8, 25_000, 6)                      # 200k steps: 3125 draws at 64, 6250 at 32
+    rc, x, st = hip.path_linear_sgd_raw(g_w, _ygs(g_w, 2))
+    assert st.bundle == 32
     rc, x, st = hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2), cfg=hip.make_config(n_streams=1))
     assert st.bundle == 1                                            # a single stream is always a reference stream
     with pytest.raises(hip.GfsError):
