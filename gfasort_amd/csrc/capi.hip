@@ -97,26 +97,44 @@ int gfs_device_count(void) {
 int gfs_warmup(int device) {
     // Creates the HIP context (the first HIP call of a process costs ~0.1-0.3 s); callers run this
     // on a side thread while they are still parsing their input.
+    const bool timing = std::getenv("GFS_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(GFS_E_HIP, "no HIP device available (libgfasort_hip has no CPU fallback)");
     if (device < 0 || device >= n) return fail(GFS_E_ARG, "bad device index");
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gfs_warmup] %-12s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
+    lap("context");
     // code objects load on first use, one per translation unit: touch each now, and the allocator too
     HIPCHK(gfs::warm_module_1d());
+    lap("module 1d");
+    HIPCHK(gfs::warm_module_index());
+    lap("module index");
     HIPCHK(gfs::warm_module_nd());
     HIPCHK(gfs::warm_module_nd_team());
-    HIPCHK(gfs::warm_module_index());
+    lap("modules nd");
     // ... and the copy paths in both directions (the first hipMemcpy of a process sets up its staging
     // buffers and DMA queues: ~0.13 s when it was left to the first upload)
     void *p = nullptr;
     std::vector<unsigned char> h(1 << 20, 0);
     HIPCHK(hipMalloc(&p, 64u << 20));
+    lap("malloc");
     HIPCHK(hipMemcpy(p, h.data(), h.size(), hipMemcpyHostToDevice));
+    lap("h2d");
     HIPCHK(hipMemset(p, 0, 64u << 20));
+    HIPCHK(hipDeviceSynchronize());
+    lap("memset");
     HIPCHK(hipMemcpy(h.data(), p, h.size(), hipMemcpyDeviceToHost));
     HIPCHK(hipDeviceSynchronize());
+    lap("d2h");
     HIPCHK(hipFree(p));
+    lap("free");
     return GFS_OK;
 }
 

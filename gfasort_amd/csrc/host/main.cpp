@@ -111,7 +111,8 @@ int main(int argc, char **argv) {
 
     bool have_layout = false;
     Layout layout;
-    if (warm.joinable()) warm.join();
+    // the warm-up thread is NOT joined here: flattening and parameter scans need no GPU, and the first HIP
+    // call of the SGD step simply waits inside the runtime for whatever initialisation is still going on
     auto t_s0 = std::chrono::steady_clock::now();
     try {
         size_t step = 0;
@@ -143,6 +144,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     t_steps = since(t_s0);
+    if (warm.joinable()) warm.join();
     auto t_w0 = std::chrono::steady_clock::now();
     if (have_layout) {
         if (!args.layout_out.empty()) {
