@@ -322,7 +322,7 @@ static int upload_zeta_table(gfs_ctx *c, const gfs_sgd_params *p, const double *
 }
 
 // Streams per launch when the caller leaves it to the library.
-static uint64_t auto_stream_count(const gfs_ctx *c) {
+static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
     // 768 lanes per CU (3 waves per SIMD): the measured optimum on MI355X for the team kernels, fused or
     // one launch per iteration, 1D and nD (profiles/r01/sweep_streams_final.log; reference streams are flat
     // within 5 % from 512 up).  Each wave is a serial chain of memory round trips, so more chains raise
@@ -333,9 +333,12 @@ static uint64_t auto_stream_count(const gfs_ctx *c) {
     // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight
     // term corrects its two nodes from positions read before the others landed, so with ~2 concurrent
     // terms per node and mu clamped at 1 the corrections overshoot — a 6000-node graph of short paths
-    // diverged (stress 1e8) under 6784 streams and converges under 1024
-    // (profiles/r01/stream_cap_probe.log).  An explicit n_streams overrides this.
-    const uint64_t by_nodes = (c->n_nodes / 4) / 64 * 64;
+    // diverged (stress 1e8) under 6784 reference streams and converges under 1024
+    // (profiles/r01/stream_cap_probe.log).  The team kernels tolerate one stream per 2 nodes: bubble graphs
+    // of 26k / 79k / 197k nodes end at stress 0.0070 / 0.0040 / 0.0031 against 0.0069 / 0.0040 / 0.0029 at one
+    // per 4, and run 1.3-1.7x faster; at one per node the largest drifts to 0.0033, at two per node to
+    // 0.0071 (profiles/r01/stream_cap_mid.log).  An explicit n_streams overrides this.
+    const uint64_t by_nodes = (c->n_nodes / (team ? 2 : 4)) / 64 * 64;
     return std::max<uint64_t>(64, std::min(chip, std::min(by_work, by_nodes)));
 }
 
@@ -401,7 +404,7 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     c->quota_total = c->cfg.term_updates_per_iteration ? c->cfg.term_updates_per_iteration : p->min_term_updates;
     c->block = c->cfg.block_size ? c->cfg.block_size : 256;
     if (c->block % 64 || c->block > 1024) return fail(GFS_E_ARG, "block_size must be a multiple of 64, <= 1024");
-    const uint64_t T = c->cfg.n_streams ? c->cfg.n_streams : auto_stream_count(c);
+    uint64_t T = c->cfg.n_streams ? c->cfg.n_streams : auto_stream_count(c, false);
     if (T > 0x7FFFFFFFull) return fail(GFS_E_ARG, "n_streams too large");
     c->n_streams = T;
     if (c->quota_total / T + 1 > 0xFFFFFFFFull) return fail(GFS_E_UNSUPPORTED, "per-stream quota exceeds 2^32");
@@ -409,6 +412,7 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     if (c->cfg.attempt_factor > 0xFFFFFFFFull) return fail(GFS_E_ARG, "attempt_factor too large");
     rc = choose_bundle(c, dims);
     if (rc) return rc;
+    if (!c->cfg.n_streams && c->bundle > 1) c->n_streams = T = auto_stream_count(c, true);   // both counts are multiples of 64
     c->atomic_loads = !(c->cfg.flags & GFS_F_PLAIN_LOADS);
     size_t lds = (size_t)c->n_paths * sizeof(uint4) + (size_t)c->zlen_staged * 8;
     c->lds_tables = !(c->cfg.flags & GFS_F_NO_LDS_TABLES) && lds <= 48 * 1024;
