@@ -746,3 +746,46 @@ def test_device_node_layout_with_unvisited_nodes_absent_steps_and_bad_indices():
     with pytest.raises(hip.GfsError) as ei:
         hip.Context(g)
     assert ei.value.code == -1 and "out of range" in str(ei.value)
+
+
+# ---- path tables too large for LDS (thousands of paths): the kernels read them from global memory ----------------
+def test_bundled_sampler_without_lds_tables_matches_oracle_mirror():
+    g = load("DRB1-3123.gfa")
+    p = _ygs(g, 5)
+    T, K, B = 256, 40, 16
+    og, op = oracle_graph(g), oracle_params(p)
+    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B)
+    x_ref = O.init_positions(og)
+    st_o.run(x_ref)
+    ctx = hip.Context(g)
+    ctx.setup_1d(p, hip.make_config(n_streams=T, trace_per_stream=K, flags=hip.F_BUNDLE(B) | hip.F_NO_LDS_TABLES))
+    ctx.upload(hip.init_positions(g))
+    ctx.run()
+    tr, _ = ctx.trace()
+    so, hst = st_o.stats(), ctx.stats()
+    assert (hst.term_updates, hst.attempts) == (so.term_updates, so.attempts)
+    tr_ref = st_o.trace.reshape(T, K)
+    assert np.array_equal(tr["i"], tr_ref["i"]) and np.array_equal(tr["j"], tr_ref["j"])
+    ctx.close()
+
+
+def test_many_paths_graph_sorts_exactly_through_the_fused_kernel():
+    """4000 paths: 64 KB of path records do not fit the 48 KB LDS budget, so the (fused) team kernel takes its
+    global-memory variant; one wave is still bit-identical fused or not, and the whole run sorts exactly."""
+    g = G.synth_windows(100_000, 4000, 2_500, 9)
+    assert g.n_paths == 4000
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    rc, x, st = hip.path_linear_sgd_raw(g, p)
+    assert rc == 0 and st.bundle == 64 and st.launches == 1
+    assert st.term_updates == (p.iter_max + 1) * p.min_term_updates
+    assert np.isfinite(x).all() and _chain_order_ok(g, x)
+    p.iter_max = 6
+    out = []
+    for extra in (0, hip.F_NO_FUSE):
+        ctx = hip.Context(g)
+        ctx.setup_1d(p, hip.make_config(n_streams=64, flags=hip.F_BUNDLE(64) | extra))
+        ctx.upload(hip.init_positions(g))
+        ctx.run()
+        out.append(ctx.download())
+        ctx.close()
+    assert np.array_equal(out[0].view(np.uint64), out[1].view(np.uint64))
