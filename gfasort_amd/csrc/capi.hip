@@ -26,6 +26,7 @@ hipError_t warm_module_1d();
 hipError_t warm_module_nd();
 hipError_t warm_module_nd_team();
 hipError_t warm_module_index();
+hipError_t init_positions_device(const uint32_t *d_node_len, const uint32_t *d_perm, double *d_x, uint64_t n);
 hipError_t reorder_positions_device(const double *d_src, double *d_dst, const uint32_t *d_perm, uint64_t N, uint32_t D,
                                     int to_device, hipStream_t st);
 hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_steps, uint64_t n_nodes, uint32_t *d_perm,
@@ -232,6 +233,7 @@ struct gfs_ctx {
     uint4 *d_path_rec = nullptr;
     uint64_t *d_path_len = nullptr;
     uint32_t *d_perm = nullptr;         // node layout on the device (dense index -> slot)
+    uint32_t *d_node_len = nullptr;     // node lengths by dense index (K4: initial positions)
     // SGD state
     int dims = 0;                      // 0 = 1D
     bool configured = false;
@@ -535,9 +537,9 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
         return fail(GFS_E_HIP, m);
     };
     const uint64_t S = g->n_steps, N = g->n_nodes, P = g->n_paths;
-    uint32_t *d_step_node = nullptr, *d_node_len = nullptr; uint8_t *d_rev = nullptr; uint64_t *d_first = nullptr, *d_tmp = nullptr;
+    uint32_t *d_step_node = nullptr; uint8_t *d_rev = nullptr; uint64_t *d_first = nullptr, *d_tmp = nullptr;
     auto free_tmp = [&]() {
-        if (d_step_node) (void)hipFree(d_step_node); if (d_node_len) (void)hipFree(d_node_len);
+        if (d_step_node) (void)hipFree(d_step_node);
         if (d_rev) (void)hipFree(d_rev); if (d_first) (void)hipFree(d_first); if (d_tmp) (void)hipFree(d_tmp);
     };
     hipError_t e;
@@ -546,6 +548,8 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     GFS_TRY("hipMalloc path_rec", hipMalloc(&c->d_path_rec, prec.size() * sizeof(uint4)));
     GFS_TRY("hipMalloc path_len", hipMalloc(&c->d_path_len, std::max<uint64_t>(P, 1) * 8));
     GFS_TRY("hipMalloc perm", hipMalloc(&c->d_perm, std::max<uint64_t>(N, 1) * 4));
+    GFS_TRY("hipMalloc node_len", hipMalloc(&c->d_node_len, std::max<uint64_t>(N, 1) * 4));
+    if (N) { GFS_TRY("hipMemcpy node_len", hipMemcpy(c->d_node_len, g->node_len, N * 4, hipMemcpyHostToDevice)); }
     GFS_TRY("hipMemcpy path_rec", hipMemcpy(c->d_path_rec, prec.data(), prec.size() * sizeof(uint4), hipMemcpyHostToDevice));
     if (S) {
         GFS_TRY("hipMalloc step_node", hipMalloc(&d_step_node, S * 4));
@@ -568,15 +572,15 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     lap("node layout");
     if (S) {
         GFS_TRY("hipMalloc step_is_rev", hipMalloc(&d_rev, S));
-        GFS_TRY("hipMalloc node_len", hipMalloc(&d_node_len, std::max<uint64_t>(N, 1) * 4));
+
         GFS_TRY("hipMalloc path_first", hipMalloc(&d_first, (P + 1) * 8));
         GFS_TRY("hipMalloc scan", hipMalloc(&d_tmp, 2 * (S + 1) * 8));
         lap("alloc tmp");
         GFS_TRY("hipMemcpy step_is_rev", hipMemcpy(d_rev, g->step_is_rev, S, hipMemcpyHostToDevice));
-        if (N) GFS_TRY("hipMemcpy node_len", hipMemcpy(d_node_len, g->node_len, N * 4, hipMemcpyHostToDevice));
+
         GFS_TRY("hipMemcpy path_first", hipMemcpy(d_first, g->path_first_step, (P + 1) * 8, hipMemcpyHostToDevice));
         lap("upload");
-        GFS_TRY("build_path_index", gfs::build_path_index_device(d_step_node, d_rev, d_node_len, c->d_perm, d_first, (uint32_t)P, S,
+        GFS_TRY("build_path_index", gfs::build_path_index_device(d_step_node, d_rev, c->d_node_len, c->d_perm, d_first, (uint32_t)P, S,
                                                                   d_tmp, c->d_step_rec, c->d_path_len));
     }
 #undef GFS_TRY
@@ -596,6 +600,7 @@ void gfs_ctx_destroy(gfs_ctx *c) {
     if (c->d_path_rec) (void)hipFree(c->d_path_rec);
     if (c->d_path_len) (void)hipFree(c->d_path_len);
     if (c->d_perm) (void)hipFree(c->d_perm);
+    if (c->d_node_len) (void)hipFree(c->d_node_len);
     delete c;
 }
 
@@ -625,6 +630,15 @@ int gfs_ctx_upload_positions(gfs_ctx *c, const double *host, uint64_t n) {
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_stage);
     if (e != hipSuccess) return fail(GFS_E_HIP, std::string("upload_positions: ") + hipGetErrorString(e));
+    return GFS_OK;
+}
+int gfs_ctx_init_positions(gfs_ctx *c) {                                  // K4, sgd.rs:286-294
+    if (!c) return fail(GFS_E_ARG, "ctx is null");
+    if (!c->d_x || c->dims != 0) return fail(GFS_E_STATE, "needs a 1D context that has been set up");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    hipError_t e = gfs::init_positions_device(c->d_node_len, c->d_perm, c->d_x, c->n_nodes);
+    if (e != hipSuccess) return fail(GFS_E_HIP, std::string("init_positions: ") + hipGetErrorString(e));
     return GFS_OK;
 }
 int gfs_ctx_download_positions(gfs_ctx *c, double *host, uint64_t n) {
@@ -907,8 +921,8 @@ static int one_shot(const gfs_graph_view *g, const gfs_sgd_params *p, int dims, 
     else { gfs_layout_params lp; lp.dimensions = (uint64_t)dims; lp.sgd = *p; rc = gfs_ctx_setup_nd(c, &lp, cfg, etas, zetas); }
     if (rc) { gfs_ctx_destroy(c); return rc; }
     lap("setup");
-    if (dims == 0 && init_x) gfs_init_positions(g, x);
-    rc = gfs_ctx_upload_positions(c, x, gfs_ctx_positions_len(c));
+    if (dims == 0 && init_x) rc = gfs_ctx_init_positions(c);             // K4 on the device
+    else rc = gfs_ctx_upload_positions(c, x, gfs_ctx_positions_len(c));
     lap("upload");
     if (!rc) rc = gfs_ctx_run(c, nullptr);
     lap("run");

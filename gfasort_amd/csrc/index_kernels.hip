@@ -1,5 +1,6 @@
 // index_kernels.hip — the one-off passes either side of the SGD loop, on the device (rocPRIM for
 // the scan and the radix sort; the kernels around them are hand-written):
+//   K4  initial positions (src/sgd.rs:286-294): exclusive prefix sum of node lengths
 //   K3  PathIndex::from_graph (src/sgd.rs:34-71): step positions = per-path exclusive prefix sum
 //       of node lengths over the steps, written straight into the 16-byte step records
 //   K6  path_sgd_sort's sort (src/sgd.rs:665-671): positions -> rank order
@@ -153,6 +154,36 @@ hipError_t reorder_positions_device(const double *d_src, double *d_dst, const ui
     if (N == 0) return hipSuccess;
     hipLaunchKernelGGL(reorder_positions_kernel, dim3(2048), dim3(256), 0, st, d_src, d_dst, d_perm, N, D, to_device);
     return hipGetLastError();
+}
+
+// ---- K4: initial 1D positions (sgd.rs:286-294): exclusive prefix sum of node lengths in node_order ---------
+__global__ void widen_len_kernel(const uint32_t *node_len, uint64_t *out, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) out[k] = node_len[k];
+}
+__global__ void scatter_prefix_kernel(const uint64_t *prefix, const uint32_t *perm, double *x, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        x[perm[k]] = (double)prefix[k];                          // the reference accumulates in usize and converts (sgd.rs:291)
+}
+// x[perm[k]] = sum of node_len[0..k).  Synchronous.
+hipError_t init_positions_device(const uint32_t *d_node_len, const uint32_t *d_perm, double *d_x, uint64_t n) {
+    if (n == 0) return hipSuccess;
+    uint64_t *d_len = nullptr, *d_scan = nullptr; void *d_tmp = nullptr;
+    hipError_t e;
+    auto done = [&](hipError_t err) { (void)hipFree(d_len); (void)hipFree(d_scan); (void)hipFree(d_tmp); return err; };
+    if ((e = hipMalloc(&d_len, n * 8)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_scan, n * 8)) != hipSuccess) return done(e);
+    hipLaunchKernelGGL(widen_len_kernel, dim3(1024), dim3(256), 0, 0, d_node_len, d_len, n);
+    size_t tmp_bytes = 0;
+    e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_len, d_scan, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), 0);
+    if (e != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8)) != hipSuccess) return done(e);
+    e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_len, d_scan, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), 0);
+    if (e != hipSuccess) return done(e);
+    hipLaunchKernelGGL(scatter_prefix_kernel, dim3(1024), dim3(256), 0, 0, d_scan, d_perm, d_x, n);
+    if ((e = hipGetLastError()) != hipSuccess) return done(e);
+    return done(hipDeviceSynchronize());
 }
 
 // ---- K6 ------------------------------------------------------------------------------------------

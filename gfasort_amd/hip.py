@@ -64,7 +64,7 @@ EXPORTS = [
     "gfs_zeta_table_len", "gfs_zeta_table", "gfs_init_positions", "gfs_init_layout_dim0",
     "gfs_sort_order", "gfs_path_linear_sgd", "gfs_path_sgd_sort", "gfs_path_linear_sgd_layout", "gfs_ctx_create",
     "gfs_ctx_create_with_layout", "gfs_ctx_node_layout",
-    "gfs_ctx_destroy", "gfs_ctx_setup_1d", "gfs_ctx_setup_nd", "gfs_ctx_positions_len",
+    "gfs_ctx_destroy", "gfs_ctx_setup_1d", "gfs_ctx_setup_nd", "gfs_ctx_positions_len", "gfs_ctx_init_positions",
     "gfs_ctx_upload_positions", "gfs_ctx_download_positions", "gfs_ctx_positions_device",
     "gfs_ctx_bind_positions", "gfs_ctx_reset_streams", "gfs_ctx_run_iteration", "gfs_ctx_run_range", "gfs_ctx_run",
     "gfs_ctx_synchronize", "gfs_ctx_stats", "gfs_ctx_sort_order", "gfs_ctx_trace", "gfs_merge_prepare", "gfs_merge_apply",
@@ -93,6 +93,7 @@ def lib():
         L.gfs_zeta_table_len.restype = C.c_uint64
         L.gfs_ctx_positions_len.restype = C.c_uint64
         L.gfs_ctx_positions_len.argtypes = [C.c_void_p]
+        L.gfs_ctx_init_positions.argtypes = [C.c_void_p]
         L.gfs_ctx_positions_device.restype = C.c_void_p
         L.gfs_ctx_positions_device.argtypes = [C.c_void_p]
         L.gfs_ctx_destroy.argtypes = [C.c_void_p]
@@ -262,6 +263,10 @@ class Context:
     def upload(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         check(lib().gfs_ctx_upload_positions(self._h, _ptr(x), x.shape[0]))
+
+    def init_positions(self):
+        """1D: the reference's initial positions, computed on the device."""
+        check(lib().gfs_ctx_init_positions(self._h))
 
     def download(self):
         x = np.zeros(self.positions_len(), dtype=np.float64)

@@ -186,6 +186,8 @@ int   gfs_ctx_setup_nd(gfs_ctx *ctx, const gfs_layout_params *p, const gfs_launc
                        const double *etas, const double *zetas);
 uint64_t gfs_ctx_positions_len(const gfs_ctx *ctx);              /* n_nodes (1D) or n_nodes*2*D */
 int   gfs_ctx_upload_positions(gfs_ctx *ctx, const double *host, uint64_t n);
+int   gfs_ctx_init_positions(gfs_ctx *ctx);                      /* 1D: the reference's start (sgd.rs:286-294),
+                                                                    prefix sum of node lengths, on the device */
 int   gfs_ctx_download_positions(gfs_ctx *ctx, double *host, uint64_t n);
 void *gfs_ctx_positions_device(gfs_ctx *ctx);                    /* device pointer (for RCCL)   */
 int   gfs_ctx_bind_positions(gfs_ctx *ctx, void *device_ptr);    /* use a caller-owned buffer   */

@@ -789,3 +789,13 @@ def test_many_paths_graph_sorts_exactly_through_the_fused_kernel():
         out.append(ctx.download())
         ctx.close()
     assert np.array_equal(out[0].view(np.uint64), out[1].view(np.uint64))
+
+
+def test_initial_positions_on_the_device_equal_the_host_prefix_sum():
+    """K4: gfs_ctx_init_positions (rocPRIM scan + scatter into the device's node order) == gfs_init_positions."""
+    for g in (load("DRB1-3123.gfa"), G.synth_bubbles(20000, 16, 5)):
+        ctx = hip.Context(g)
+        ctx.setup_1d(_ygs(g, 2), hip.make_config(n_streams=64))
+        ctx.init_positions()
+        assert np.array_equal(ctx.download(), hip.init_positions(g))
+        ctx.close()
