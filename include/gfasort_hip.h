@@ -95,9 +95,9 @@ typedef struct gfs_launch_config {
 #define GFS_F_PLAIN_LOADS   1u        /* read positions with plain (L2-cacheable) loads instead
                                          of agent-scope relaxed atomic loads                 */
 #define GFS_F_NO_LDS_TABLES 2u        /* keep zeta/path tables in global memory              */
-/* Sampling bundle (1D): n adjacent lanes share ONE sampled (step a, jump) drawn by the bundle's
- * first lane — an ordinary reference stream — and take n consecutive steps of the path with the
- * same signed jump, so that record loads, position loads and atomics of a bundle coalesce into a
+/* Sampling bundle: n adjacent lanes share ONE sampled (step a, jump) drawn by an ordinary reference
+ * stream and take n consecutive steps of the path with the same signed jump (nD, D <= 3: and the same
+ * pair of end flips), so that record loads, position loads and atomics of a bundle coalesce into a
  * few 64-B requests (gfasort_amd/csrc/sgd_device.h).  n = 1: reference streams, every lane is a
  * reference worker thread.  n = 0 (default): the library picks by graph size — 1 for small
  * graphs (< 16384 nodes), else up to 64 while an iteration still has >= 4096 independent draws. */
