@@ -119,7 +119,6 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
         }
         uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
         if (valid) { ra = a.step_rec[sa]; rb = a.step_rec[sb]; }
-#pragma unroll 2
         for (int t = t0; t < B; ++t) {
             // request the records of trip t+1
             uint64_t sa_n = 0, sb_n = 0; bool valid_n = false;
