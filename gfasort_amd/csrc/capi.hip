@@ -574,7 +574,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
         GFS_TRY("hipMalloc step_is_rev", hipMalloc(&d_rev, S));
 
         GFS_TRY("hipMalloc path_first", hipMalloc(&d_first, (P + 1) * 8));
-        GFS_TRY("hipMalloc scan", hipMalloc(&d_tmp, 2 * (S + 1) * 8));
+        GFS_TRY("hipMalloc scan", hipMalloc(&d_tmp, (S + 1) * 8));
         lap("alloc tmp");
         GFS_TRY("hipMemcpy step_is_rev", hipMemcpy(d_rev, g->step_is_rev, S, hipMemcpyHostToDevice));
 

@@ -9,19 +9,23 @@
 #include <stdint.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace gfs {
 
 // ---- K3 ------------------------------------------------------------------------------------------
-// len[s] = sequence length of the step's node (0 for an absent node, sgd.rs:52-54); len[S] = 0
-__global__ void step_len_kernel(const uint32_t *step_node, const uint32_t *node_len, uint64_t *len, uint64_t n_steps) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= n_steps; s += stride) {
-        uint64_t l = 0;
-        if (s < n_steps) { const uint32_t n = step_node[s]; if (n != 0xFFFFFFFFu) l = node_len[n]; }
-        len[s] = l;
+// len(s) = sequence length of the step's node (0 for an absent node, sgd.rs:52-54); len(S) = 0.  Fed to the
+// scan through a transform iterator, so the lengths are never materialised (8 B per step less scratch).
+struct StepLen {
+    const uint32_t *step_node, *node_len;
+    uint64_t n_steps;
+    __host__ __device__ uint64_t operator()(uint64_t s) const {
+        if (s >= n_steps) return 0;
+        const uint32_t n = step_node[s];
+        return n == 0xFFFFFFFFu ? 0ull : (uint64_t)node_len[n];
     }
-}
+};
 
 // rec[s] = { internal node slot | NO_NODE, path | rev<<31, pos lo, pos hi } with pos = scan[s] - scan[first(path)]
 __global__ void fill_records_kernel(const uint32_t *step_node, const uint8_t *step_is_rev, const uint32_t *perm,
@@ -47,20 +51,20 @@ __global__ void path_len_kernel(const uint64_t *scan, const uint64_t *path_first
     if (p < n_paths) path_len[p] = scan[path_first[p + 1]] - scan[path_first[p]];
 }
 
-// All pointers are device pointers; tmp holds 2*(n_steps+1) u64 (len, scan).  Synchronous.
+// All pointers are device pointers; tmp holds (n_steps+1) u64 (the scan).  Synchronous.
 hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
                                    const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
                                    uint64_t n_steps, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len) {
-    uint64_t *d_len = d_tmp, *d_scan = d_tmp + (n_steps + 1);
+    uint64_t *d_scan = d_tmp;
     const unsigned blocks = 2048;
-    hipLaunchKernelGGL(step_len_kernel, dim3(blocks), dim3(256), 0, 0, d_step_node, d_node_len, d_len, n_steps);
+    auto lens = rocprim::make_transform_iterator(rocprim::counting_iterator<uint64_t>(0), StepLen{d_step_node, d_node_len, n_steps});
     size_t tmp_bytes = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_len, d_scan, (uint64_t)0, (size_t)(n_steps + 1),
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, lens, d_scan, (uint64_t)0, (size_t)(n_steps + 1),
                                            rocprim::plus<uint64_t>(), 0);
     if (e != hipSuccess) return e;
     void *d_scan_tmp = nullptr;
     if ((e = hipMalloc(&d_scan_tmp, tmp_bytes ? tmp_bytes : 8)) != hipSuccess) return e;
-    e = rocprim::exclusive_scan(d_scan_tmp, tmp_bytes, d_len, d_scan, (uint64_t)0, (size_t)(n_steps + 1),
+    e = rocprim::exclusive_scan(d_scan_tmp, tmp_bytes, lens, d_scan, (uint64_t)0, (size_t)(n_steps + 1),
                                 rocprim::plus<uint64_t>(), 0);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(fill_records_kernel, dim3(blocks), dim3(256), 0, 0, d_step_node, d_step_is_rev, d_perm, d_scan,
@@ -226,7 +230,7 @@ hipError_t sort_order_device(const double *d_x_layout, const uint32_t *d_perm, u
 // loads this translation unit's code object (HIP loads modules on first use); see gfs_warmup
 hipError_t warm_module_index() {
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&step_len_kernel));
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&path_len_kernel));
 }
 
 }  // namespace gfs
