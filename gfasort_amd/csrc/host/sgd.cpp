@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <iostream>
@@ -182,18 +185,34 @@ std::unordered_map<size_t, double> path_linear_sgd(const BidirectedGraph &g, con
     return positions;
 }
 
+namespace {
+struct Lap {                                                        // GFS_TIMING=1: phase times on stderr
+    bool on = std::getenv("GFS_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[sgd_sort] %-14s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
+
 std::vector<Handle> path_sgd_sort(const BidirectedGraph &g, const PathSGDParams &p, const HipOptions &opt,
                                   gfs_stats *stats) {
     // same result as sorting path_linear_sgd's map (sgd.rs:641-672); the sort runs on the device
     std::vector<Handle> out;
     if (g.node_count() == 0) return out;                             // sgd.rs:242-244
+    Lap lap;
     FlatGraph f = g.flatten();
+    lap("flatten");
     gfs_graph_view v = f.view();
     gfs_sgd_params cp = p.to_c();
     std::vector<double> x(f.node_len.size());
     std::vector<uint64_t> order(x.size());
     gfs_stats st;
     int rc = gfs_path_sgd_sort(&v, &cp, &opt.cfg, nullptr, nullptr, 1, x.data(), order.data(), &st);
+    lap("gfs_path_sgd_sort");
     check(rc);
     if (stats) *stats = st;
     if (rc == GFS_NOTHING_TO_DO) {
@@ -202,13 +221,16 @@ std::vector<Handle> path_sgd_sort(const BidirectedGraph &g, const PathSGDParams 
     }
     out.reserve(order.size());
     for (uint64_t idx : order) out.push_back(Handle::forward(f.node_ids[idx]));   // idx -> handle, sgd.rs:649-662
+    lap("handles");
     return out;
 }
 
 void sgd_sort_only(BidirectedGraph &g, const PathSGDParams &p, uint8_t verbose, const HipOptions &opt, gfs_stats *stats) {
     if (verbose >= 2) std::cerr << "[path_sgd] Starting path-guided SGD\n";
     auto ordering = path_sgd_sort(g, p, opt, stats);
+    Lap lap;
     g.apply_ordering(ordering);
+    lap("apply_ordering");
     if (verbose >= 2) std::cerr << "[path_sgd] Complete\n";
 }
 

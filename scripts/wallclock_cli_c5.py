@@ -14,7 +14,7 @@ def main():
         t0 = time.time()
         r = subprocess.run([B.CLI, "-i", src, "-o", dst, "-p", "Y", "-v", "1"], capture_output=True, text=True)
         print("rc", r.returncode, f"wall {time.time() - t0:.2f}s  output {os.path.getsize(dst) / 1e9:.2f} GB")
-        print("\n".join(l for l in r.stderr.split("\n") if "term updates" in l or "done" in l or "loaded" in l))
+        print("\n".join(l for l in r.stderr.split("\n") if "term updates" in l or "done" in l or "loaded" in l or " ms" in l))
     # the sorted file lists the nodes in chain order: S lines carry ids 1..N, path steps ascend or descend by 1
     with open(dst) as fh:
         for line in fh:
