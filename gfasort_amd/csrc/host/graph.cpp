@@ -172,21 +172,37 @@ void BidirectedGraph::apply_ordering(const std::vector<Handle> &ordering) {
     size_t max_new = 0;
     for (size_t v : old_to_new) max_new = std::max(max_new, v);
     std::vector<std::optional<BiNode>> new_nodes(max_new + 1);
-    for (size_t id = 0; id < nodes.size(); ++id) {
-        size_t nid = lookup(id);
-        if (nid && nodes[id].has_value()) {
-            BiNode n = std::move(*nodes[id]);
-            n.id = nid;
-            n.rank = (uint64_t)(nid - 1);                          // 0-based rank
-            new_nodes[nid] = std::move(n);
-        }
+    {
+        // an ordering names a node at most once in practice; when it does not, the last occurrence's slot is the one
+        // old_to_new holds, so every old node still has exactly one target and the moves are independent
+        const size_t BLOCK = (size_t)1 << 16;
+        parallel_for((nodes.size() + BLOCK - 1) / BLOCK, [&](size_t b) {
+            for (size_t id = b * BLOCK; id < std::min(nodes.size(), (b + 1) * BLOCK); ++id) {
+                size_t nid = lookup(id);
+                if (nid && nodes[id].has_value()) {
+                    BiNode n = std::move(*nodes[id]);
+                    n.id = nid;
+                    n.rank = (uint64_t)(nid - 1);                  // 0-based rank
+                    new_nodes[nid] = std::move(n);
+                }
+            }
+        });
     }
     nodes = std::move(new_nodes);
-    std::vector<BiEdge> relabelled;
-    relabelled.reserve(edges.size());
-    for (const auto &e : edges) {
-        size_t f = lookup(e.from.node_id()), t = lookup(e.to.node_id());
-        if (f && t) relabelled.push_back(BiEdge{Handle::make(f, e.from.is_reverse()), Handle::make(t, e.to.is_reverse())});
+    std::vector<BiEdge> relabelled(edges.begin(), edges.end());
+    {
+        std::vector<uint8_t> keep(relabelled.size(), 0);
+        const size_t BLOCK = (size_t)1 << 16;
+        parallel_for((relabelled.size() + BLOCK - 1) / BLOCK, [&](size_t b) {
+            for (size_t k = b * BLOCK; k < std::min(relabelled.size(), (b + 1) * BLOCK); ++k) {
+                const BiEdge e = relabelled[k];
+                size_t f = lookup(e.from.node_id()), t = lookup(e.to.node_id());
+                if (f && t) { relabelled[k] = BiEdge{Handle::make(f, e.from.is_reverse()), Handle::make(t, e.to.is_reverse())}; keep[k] = 1; }
+            }
+        });
+        size_t n = 0;
+        for (size_t k = 0; k < relabelled.size(); ++k) if (keep[k]) relabelled[n++] = relabelled[k];
+        relabelled.resize(n);
     }
     EdgeSet new_edges;
     new_edges.reserve(relabelled.size());
@@ -215,6 +231,24 @@ inline void put_uint(std::string &b, uint64_t v) {
 }
 }  // namespace
 
+namespace {
+// items [0, n) in blocks of `block`: fmt(lo, hi, text) appends the block's text (host threads, a bounded window of
+// blocks at a time); the blocks are written in order
+void write_blocks(std::ostream &out, size_t n, size_t block, const std::function<void(size_t, size_t, std::string &)> &fmt) {
+    const size_t nblocks = (n + block - 1) / block;
+    const size_t window = std::max<size_t>(io_threads() * 4, 1);
+    std::vector<std::string> piece(std::min(window, std::max<size_t>(nblocks, 1)));
+    for (size_t base = 0; base < nblocks; base += window) {
+        const size_t cnt = std::min(window, nblocks - base);
+        parallel_for(cnt, [&](size_t i) {
+            piece[i].clear();
+            fmt((base + i) * block, std::min(n, (base + i + 1) * block), piece[i]);
+        });
+        for (size_t i = 0; i < cnt; ++i) out.write(piece[i].data(), (std::streamsize)piece[i].size());
+    }
+}
+}  // namespace
+
 void BidirectedGraph::write_gfa(std::ostream &out) const {
     // one growing buffer, flushed in 8 MB pieces (the step lists of long paths are the bulk)
     const bool timing = std::getenv("GFS_TIMING") != nullptr;
@@ -229,11 +263,13 @@ void BidirectedGraph::write_gfa(std::ostream &out) const {
     b.reserve(9u << 20);
     auto flush = [&](bool force) { if (force || b.size() > (8u << 20)) { out.write(b.data(), (std::streamsize)b.size()); b.clear(); } };
     b += "H\tVN:Z:1.0\n";
-    for (size_t id = 0; id < nodes.size(); ++id)
-        if (nodes[id].has_value()) {
-            b += "S\t"; put_uint(b, id); b.push_back('\t'); b += nodes[id]->sequence; b.push_back('\n');
-            flush(false);
-        }
+    flush(true);
+    write_blocks(out, nodes.size(), (size_t)1 << 16, [&](size_t lo, size_t hi, std::string &o) {
+        for (size_t id = lo; id < hi; ++id)
+            if (nodes[id].has_value()) {
+                o += "S\t"; put_uint(o, id); o.push_back('\t'); o += nodes[id]->sequence; o.push_back('\n');
+            }
+    });
     lap("S");
     std::vector<BiEdge> es(edges.begin(), edges.end());
     lap("L copy");
@@ -251,13 +287,15 @@ void BidirectedGraph::write_gfa(std::ostream &out) const {
             });
     }
     lap("L sort");
-    for (const auto &e : es) {
-        b += "L\t"; put_uint(b, e.from.node_id()); b.push_back('\t'); b.push_back(e.from.orientation_char());
-        b.push_back('\t'); put_uint(b, e.to.node_id()); b.push_back('\t'); b.push_back(e.to.orientation_char());
-        b += "\t0M\n";
-        flush(false);
-    }
-    flush(true);
+    write_blocks(out, es.size(), (size_t)1 << 16, [&](size_t lo, size_t hi, std::string &o) {
+        o.reserve((hi - lo) * 28);
+        for (size_t k = lo; k < hi; ++k) {
+            const BiEdge &e = es[k];
+            o += "L\t"; put_uint(o, e.from.node_id()); o.push_back('\t'); o.push_back(e.from.orientation_char());
+            o.push_back('\t'); put_uint(o, e.to.node_id()); o.push_back('\t'); o.push_back(e.to.orientation_char());
+            o += "\t0M\n";
+        }
+    });
     lap("L");
     // step lists: formatted in pieces by the host threads, a bounded window of pieces at a time, written in order
     const auto chunks = step_chunks(paths, (size_t)1 << 17);
