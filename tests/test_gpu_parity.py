@@ -801,3 +801,57 @@ def test_initial_positions_on_the_device_equal_the_host_prefix_sum():
         ctx.init_positions()
         assert np.array_equal(ctx.download(), hip.init_positions(g))
         ctx.close()
+
+
+# ---- the N>1 path for the layout step: two ranks share the one GPU over gloo, D = 2 ------------------------------
+def _mp_rank_nd(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gfasort_amd.distributed import ShardedSGD, hip_engine_factory
+    from gfasort_amd import sgd as S
+    g = G.synth_bubbles(20000, 16, 5)
+    p = P.LayoutSGDParams.from_graph(g, 2, 1)
+    r = ShardedSGD(g, p, rank, world, hip_engine_factory(device_index=0), dims=2, dist=dist, merge_every=2)
+    r.set_positions(S.default_layout_init(g, 2, p.seed).ravel())
+    r.run()
+    torch.cuda.synchronize()
+    c = r.positions_numpy()
+    st = r.engine.stats()
+    cs = [torch.zeros(c.shape[0], dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(cs, torch.from_numpy(c))
+    upd = torch.tensor([float(st.term_updates)], dtype=torch.float64)
+    dist.all_reduce(upd)
+    if rank == 0:
+        out.put((c, [t.numpy() for t in cs], float(upd.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_layout_2d():
+    import socket
+    import torch.multiprocessing as mp
+    from gfasort_amd import sgd as S
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_mp_rank_nd, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    c, cs, upd = out.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    g = G.synth_bubbles(20000, 16, 5)
+    p = P.LayoutSGDParams.from_graph(g, 2, 1)
+    assert np.array_equal(cs[0], cs[1]) and upd == (p.iter_max + 1) * p.min_term_updates
+    og = oracle_graph(g)
+    c0 = S.default_layout_init(g, 2, p.seed)
+    lay1, _ = S.path_linear_sgd_layout(g, p, return_stats=True)
+    s0 = O.layout_stress(og, 2, c0, 100000)
+    s1 = O.layout_stress(og, 2, lay1.coords, 100000)
+    s2 = O.layout_stress(og, 2, c.reshape(-1, 2, 2), 100000)
+    assert np.isfinite(c).all() and s1 < 0.1 * s0 and s2 < 0.1 * s0 and s2 < 2.0 * s1 + 1e-3, (s0, s1, s2)
