@@ -507,7 +507,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     // order the paths first step on them, unvisited nodes last; derived on the device, index_kernels.hip)
     // unless the caller supplies a layout: consecutive steps of a path then touch neighbouring position words whatever the
     // order of the input's S lines was, which is what lets a run's loads and atomics coalesce
-    // (C3: 47 G updates/s in path order, 10 G/s with randomly ordered nodes).
+    // (C3 with randomly ordered nodes: 63 G updates/s in path order, 11 G/s in input order).
     c->perm.assign(g->n_nodes, 0xFFFFFFFFu);
     if (node_perm) {
         std::vector<uint8_t> seen(g->n_nodes, 0);
