@@ -241,6 +241,21 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
         L.rb0 = rng.uniform32(L.cnt, pr.z);                                            // :493-494
     }
     L.ok = (L.rb0 != L.ra0) ? 1u : 0u;                                                 // :497
+    if (L.ok && L.cnt >= 2u * a.bundle && r0.x != 0xFFFFFFFFu) {        // only where a run will be expanded
+        // Line-aligned runs, for jumps of 64 steps or more.  The run that expand_run builds around this leader then
+        // starts `sh` steps before it, where sh = the leader node's slot mod 8, so that along a path laid out in slot
+        // order the run's first position word opens a 64-B line (8 instead of 8.9 lines per 64 lanes on that side).
+        // The jump is NOT touched: truncating it to a multiple of 8 would line up the partner run as well (74 instead
+        // of 71 G updates/s on C3), but then every long-range term joins two nodes of the same residue class mod 8 and
+        // the classes drift against each other — a 20 000-node chain no longer came out in exact order.  Shorter
+        // jumps are left alone altogether: there only some lanes act (node-disjoint rule) and a fixed phase would
+        // leave some neighbour pairs never sampled.  Applied only when both ends stay inside the path.
+        const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0;
+        if (jump >= 64 || jump <= -64) {
+            const uint32_t sh = r0.x & 7u;
+            if (L.ra0 >= sh && L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
+        }
+    }
     return L;
 }
 

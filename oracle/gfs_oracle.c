@@ -527,6 +527,7 @@ struct gfo_state {
     uint64_t T, D, quota_total, attempt_factor, bundle;
     uint64_t *rng, *done, *att, *ntr;
     struct leader_s *lead; uint8_t *lead_left, *lead_cool;   /* 1D bundled mode: each wave's partly expanded pass */
+    uint32_t *node_slot;                                     /* bundled mode: the product's internal node layout (line-aligned runs) */
     gfo_term *trace; uint64_t trace_per_stream;
     uint64_t total_upd, total_att, iterations;
     double seconds;
@@ -536,7 +537,7 @@ void gfo_state_destroy(gfo_state *s) {
     if (!s) return;
     pidx_free(&s->pi);
     free(s->etas); free(s->zetas); free(s->rng); free(s->done); free(s->att); free(s->ntr);
-    free(s->lead); free(s->lead_left); free(s->lead_cool);
+    free(s->lead); free(s->lead_left); free(s->lead_cool); free(s->node_slot);
     free(s);
 }
 
@@ -577,6 +578,19 @@ int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas
  * flips).  Updates of one trip are applied here in lane order; the GPU applies them concurrently
  * (and one trip late).
  * ---------------------------------------------------------------------------------------- */
+/* The product aligns runs to the 64-B lines of ITS position vector, i.e. by its internal node layout
+ * (gfs_ctx_node_layout): slot[k] for dense node k.  NULL = identity. */
+int gfo_state_set_node_slots(gfo_state *s, const uint32_t *slot) {
+    if (!s) return -1;
+    free(s->node_slot); s->node_slot = NULL;
+    if (slot) {
+        s->node_slot = (uint32_t *)malloc(s->pi.n_nodes * sizeof(uint32_t));
+        if (!s->node_slot) return -2;
+        memcpy(s->node_slot, slot, s->pi.n_nodes * sizeof(uint32_t));
+    }
+    return 0;
+}
+
 int gfo_state_set_bundle(gfo_state *s, uint64_t bundle) {
     if (!s) return -1;
     if (bundle == 0) bundle = 1;
@@ -653,6 +667,16 @@ static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t
         L.rb0 = uniform_usize(rng, L.cnt);                                             /* :493-494 */
     }
     L.ok = L.rb0 != L.ra0;                                                             /* :497 */
+    /* line-aligned runs (product: sgd_device.h sample_leader): the run starts (slot of the leader's node) mod 8
+     * steps before the leader (same jump) — for jumps of >= 64 steps only */
+    uint32_t node0 = pi->rec[s0].node;
+    if (L.ok && L.cnt >= 2 * s->bundle && node0 != GFO_NO_NODE) {        /* only where a run will be expanded */
+        const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0;
+        if (jump >= 64 || jump <= -64) {                               /* shorter jumps are left alone */
+            const uint64_t sh = (s->node_slot ? s->node_slot[node0] : node0) & 7u;
+            if (L.ra0 >= sh && L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
+        }
+    }
     return L;
 }
 

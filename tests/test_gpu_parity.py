@@ -257,6 +257,14 @@ def test_c5_scale_10m_nodes_100m_steps():
 
 
 # ---- bundled ("run") sampling: exact mirror check of the sampler, then quality ---------------------------
+def _node_slots(g):
+    """The product's internal node layout (first-visit path order; test_internal_node_layout_... pins the device's
+    to this): the bundled sampler aligns its runs to the 64-B lines of the position vector, so the mirror needs it."""
+    from gfasort_amd.distributed import path_order_layout
+    return path_order_layout(g)
+
+
+
 @pytest.mark.parametrize("B", [4, 8, 16, 32, 64])
 def test_bundled_sampler_trace_matches_oracle_mirror(B):
     """The bundled sampler's random-number consumption and emitted terms equal the oracle's mirror of
@@ -265,7 +273,7 @@ def test_bundled_sampler_trace_matches_oracle_mirror(B):
     p = _ygs(g, 6)
     T, K = 512, 48
     og, op = oracle_graph(g), oracle_params(p)
-    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B)
+    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g))
     x_ref = O.init_positions(og)
     st_o.run(x_ref)
     so = st_o.stats()
@@ -345,7 +353,7 @@ def test_bundled_nd_sampler_trace_matches_oracle_mirror(B, dims):
     og, op = oracle_graph(g), oracle_params(p)
     c0 = gaussian_init(g, dims, 11)
     c_ref = c0.copy()
-    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B)
+    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g))
     st_o.run(c_ref)
     so = st_o.stats()
     ctx = hip.Context(g)
@@ -607,7 +615,7 @@ def test_wide_index_path_matches_oracle(bundle):
     og, op = oracle_graph(g), oracle_params(p)
     O.lib().gfo_set_force_wide_steps(1)
     try:
-        st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=bundle)
+        st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=bundle, node_slots=_node_slots(g))
         x_ref = O.init_positions(og)
         st_o.run(x_ref)
         so = st_o.stats()
@@ -756,7 +764,7 @@ def test_bundled_sampler_without_lds_tables_matches_oracle_mirror():
     p = _ygs(g, 5)
     T, K, B = 256, 40, 16
     og, op = oracle_graph(g), oracle_params(p)
-    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B)
+    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g))
     x_ref = O.init_positions(og)
     st_o.run(x_ref)
     ctx = hip.Context(g)
