@@ -159,6 +159,23 @@ def wall_clock_leg(g):
     return out
 
 
+class _StdoutToStderr:
+    """File-descriptor level: libraries that print banners on stdout (RCCL prints its version block when the
+    first communicator is created) must not end up next to the ONE JSON line this script owes its caller."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,11 +213,16 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+        with _StdoutToStderr():
+            if share:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            # first collective here: communicator creation (and its banner) happens under the redirection
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
 
     g, p = build_workload()
     M = int(p.min_term_updates)
