@@ -212,7 +212,8 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
 struct Leader {            // one sampled leader term (per lane, registers)
     uint32_t first_lo, first_hi, cnt;   // PathInfo of its path (first_step is 64-bit)
     uint32_t ra0, rb0;     // ranks of step a and step b
-    uint32_t ok;           // 0 = the reference `continue`d (cnt == 1 or rank_a == rank_b)
+    uint32_t ok;           // bit 0: 0 = the reference `continue`d (cnt == 1 or rank_a == rank_b);
+                           // bit 1: both runs line-aligned, bits 2..4: lane rotation r (sample_leader)
 };
 
 template <bool LDS_TABLES>
@@ -241,19 +242,32 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
         L.rb0 = rng.uniform32(L.cnt, pr.z);                                            // :493-494
     }
     L.ok = (L.rb0 != L.ra0) ? 1u : 0u;                                                 // :497
-    if (L.ok && L.cnt >= 2u * a.bundle && r0.x != 0xFFFFFFFFu) {        // only where a run will be expanded
-        // Line-aligned runs, for jumps of 64 steps or more.  The run that expand_run builds around this leader then
-        // starts `sh` steps before it, where sh = the leader node's slot mod 8, so that along a path laid out in slot
-        // order the run's first position word opens a 64-B line (8 instead of 8.9 lines per 64 lanes on that side).
-        // The jump is NOT touched: truncating it to a multiple of 8 would line up the partner run as well (74 instead
-        // of 71 G updates/s on C3), but then every long-range term joins two nodes of the same residue class mod 8 and
-        // the classes drift against each other — a 20 000-node chain no longer came out in exact order.  Shorter
-        // jumps are left alone altogether: there only some lanes act (node-disjoint rule) and a fixed phase would
-        // leave some neighbour pairs never sampled.  Applied only when both ends stay inside the path.
+    if (L.ok && L.cnt >= 2u * a.bundle && r0.x != 0xFFFFFFFFu && !(a.dbg & 0x10u)) {        // only where a run will be expanded
+        // Line-aligned runs, for jumps well beyond the run length.  Along a path laid out in slot order, a run that
+        // starts on a multiple of 8 slots covers 8 lines of the position vector instead of 8.9.
+        //  * The run starts sh = (slot of the leader's node) mod 8 steps before the leader (the leader's own term
+        //    stays in the run, at lane sh).  (Bundles of 4 align to 4 slots: with 8 the leader could fall outside its
+        //    own run and half of the nodes would never lead a long-range term.)
+        //  * The partner run is a B-step block that starts zp = jump - r steps after it, r = jump mod 8, so it opens a
+        //    line too, and lane l is paired with the block's step (l + r) mod B.  Lanes l < B - r keep EXACTLY the
+        //    sampled jump; the last r <= 7 lanes wrap to the block's first steps, i.e. their jump is B steps shorter
+        //    (or longer, for a backward jump) — about one long-range term in 18 moves by one run length.
+        //  * Needs both blocks inside the path and apart (|zp| >= B); otherwise only the first rule is applied, and
+        //    jumps shorter than B + 8 are left alone altogether (there only some lanes act — node-disjoint rule — and
+        //    a fixed phase would leave some neighbour pairs never sampled).
+        // C3: 0.30 -> 0.26 atomic requests per update, 68 -> 74 G updates/s.
         const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0;
-        if (jump >= 64 || jump <= -64) {
-            const uint32_t sh = r0.x & 7u;
-            if (L.ra0 >= sh && L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
+        const int64_t Bn = (int64_t)a.bundle;
+        if (jump >= Bn + 8 || jump <= -(Bn + 8)) {
+            const int64_t A = a.bundle < 8u ? (int64_t)a.bundle : 8;               // runs shorter than a line: align to the run length
+            const uint32_t sh = r0.x & (uint32_t)(A - 1);
+            if (L.ra0 >= sh) {
+                const int64_t na = (int64_t)L.ra0 - (int64_t)sh;
+                const int64_t r = ((jump % A) + A) % A, zp = jump - r, nb = na + zp;
+                if (!(a.dbg & 0x20u) && na + Bn <= (int64_t)L.cnt && nb >= 0 && nb + Bn <= (int64_t)L.cnt && (zp >= Bn || zp <= -Bn)) {
+                    L.ra0 = (uint32_t)na; L.rb0 = (uint32_t)nb; L.ok = 1u | 2u | ((uint32_t)r << 2);
+                } else if (L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
+            }
         }
     }
     return L;
@@ -264,7 +278,12 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
 template <int B>
 __device__ __forceinline__ bool expand_run(uint32_t ok, uint64_t first, uint32_t cnt, uint32_t ra0, uint32_t rb0,
                                            int sub, uint64_t &sa, uint64_t &sb) {
-    if (!ok) return false;
+    if (!(ok & 1u)) return false;
+    if (ok & 2u) {                                                                     // both runs line-aligned blocks inside the path
+        sa = first + ra0 + (uint32_t)sub;
+        sb = first + rb0 + (((uint32_t)sub + ((ok >> 2) & 7u)) & (uint32_t)(B - 1));
+        return true;
+    }
     uint32_t ra_l = ra0, rb_l = rb0;
     if (sub != 0) {
         if (cnt < 2u * B) return false;                                                // short path: leader only

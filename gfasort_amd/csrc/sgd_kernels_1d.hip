@@ -189,14 +189,14 @@ __device__ __forceinline__ void load_pass(const KArgs &a, uint32_t tid, TeamStat
     ts.L.first_lo = a.lead[tid]; ts.L.first_hi = a.lead[T + tid]; ts.L.cnt = a.lead[2 * T + tid];
     ts.L.ra0 = a.lead[3 * T + tid]; ts.L.rb0 = a.lead[4 * T + tid];
     const uint32_t w = a.lead[5 * T + tid];
-    ts.L.ok = w & 1u; ts.left = (w >> 8) & 0xFFu; ts.cool = (w >> 16) & 1u;
+    ts.L.ok = w & 0xFFu; ts.left = (w >> 8) & 0xFFu; ts.cool = (w >> 16) & 1u;
 }
 __device__ __forceinline__ void store_pass(const KArgs &a, uint32_t tid, const TeamState &ts) {
     if (!a.lead) return;
     const uint64_t T = a.n_streams;
     a.lead[tid] = ts.L.first_lo; a.lead[T + tid] = ts.L.first_hi; a.lead[2 * T + tid] = ts.L.cnt;
     a.lead[3 * T + tid] = ts.L.ra0; a.lead[4 * T + tid] = ts.L.rb0;
-    a.lead[5 * T + tid] = (ts.L.ok & 1u) | (ts.left << 8) | (ts.cool << 16);
+    a.lead[5 * T + tid] = (ts.L.ok & 0xFFu) | (ts.left << 8) | (ts.cool << 16);
 }
 
 __device__ __forceinline__ uint64_t wave_quota_of(const KArgs &a, uint32_t tid) {

@@ -638,7 +638,7 @@ static int term_nd_flips(const pidx *pi, const iter_state *it, int fa, int fb, u
     return 1;
 }
 
-typedef struct leader_s { uint64_t first, cnt, ra0, rb0; int ok; } leader_t;
+typedef struct leader_s { uint64_t first, cnt, ra0, rb0; int ok, aligned, rot; } leader_t;
 
 /* one leader term from one reference stream: sgd.rs:444-497 without applying it */
 static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t *rng) {
@@ -647,7 +647,7 @@ static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t
     uint64_t s0 = uniform_steps(rng, pi->n_steps);                                     /* :444 */
     uint64_t path = pi->rec[s0].path_rev & 0x7FFFFFFFu;
     L.first = pi->paths[path].first_step; L.cnt = pi->paths[path].step_count;
-    L.ra0 = s0 - L.first; L.rb0 = L.ra0; L.ok = 0;
+    L.ra0 = s0 - L.first; L.rb0 = L.ra0; L.ok = 0; L.aligned = 0; L.rot = 0;
     if (L.cnt == 1) return L;                                                          /* :448 */
     if (it->cooling || flip(rng) == 1) {                                               /* :456 */
         if (L.ra0 > 0 && (flip(rng) == 1 || L.ra0 == L.cnt - 1)) {                    /* :460 */
@@ -667,14 +667,22 @@ static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t
         L.rb0 = uniform_usize(rng, L.cnt);                                             /* :493-494 */
     }
     L.ok = L.rb0 != L.ra0;                                                             /* :497 */
-    /* line-aligned runs (product: sgd_device.h sample_leader): the run starts (slot of the leader's node) mod 8
-     * steps before the leader (same jump) — for jumps of >= 64 steps only */
+    /* line-aligned runs (product: sgd_device.h sample_leader, which explains the rule): for |jump| >= B + 8 the run
+     * starts (slot of the leader's node) mod 8 steps before the leader; the partner run is the B-step block jump - r
+     * steps further on, r = jump mod 8, with lane l paired to its step (l + r) mod B */
     uint32_t node0 = pi->rec[s0].node;
     if (L.ok && L.cnt >= 2 * s->bundle && node0 != GFO_NO_NODE) {        /* only where a run will be expanded */
-        const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0;
-        if (jump >= 64 || jump <= -64) {                               /* shorter jumps are left alone */
-            const uint64_t sh = (s->node_slot ? s->node_slot[node0] : node0) & 7u;
-            if (L.ra0 >= sh && L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
+        const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0, Bn = (int64_t)s->bundle;
+        if (jump >= Bn + 8 || jump <= -(Bn + 8)) {                     /* shorter jumps are left alone */
+            const int64_t A = Bn < 8 ? Bn : 8;                            /* runs shorter than a line: align to the run length */
+            const uint64_t sh = (s->node_slot ? s->node_slot[node0] : node0) & (uint64_t)(A - 1);
+            if (L.ra0 >= sh) {
+                const int64_t na = (int64_t)L.ra0 - (int64_t)sh;
+                const int64_t r = ((jump % A) + A) % A, zp = jump - r, nb = na + zp;
+                if (na + Bn <= (int64_t)L.cnt && nb >= 0 && nb + Bn <= (int64_t)L.cnt && (zp >= Bn || zp <= -Bn)) {
+                    L.ra0 = (uint64_t)na; L.rb0 = (uint64_t)nb; L.aligned = 1; L.rot = (int)r;
+                } else if (L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
+            }
         }
     }
     return L;
@@ -728,7 +736,9 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                         valid[l] = 0;
                         if (!ld->ok) continue;
                         uint64_t ra = ld->ra0, rb = ld->rb0;
-                        if (sub != 0) {
+                        if (ld->aligned) {                              /* both runs are aligned blocks inside the path */
+                            ra = ld->ra0 + sub; rb = ld->rb0 + ((sub + (uint64_t)ld->rot) % B);
+                        } else if (sub != 0) {
                             if (ld->cnt < 2 * B) continue;
                             if (zabs < B && ((sub / zabs) & 1)) continue;
                             ra = ld->ra0 + sub;
