@@ -697,7 +697,7 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
     a.dbg = (c->cfg.flags >> 8) & 0x7Fu;             // bit 0x40 = GFS_F_DBG_WIDE_INDEX >> 8
-    if (4 * c->n_streams <= c->n_nodes) a.dbg |= 0x80u;      // team kernel: defer atomics by one trip
+    if (4 * c->n_streams <= c->n_nodes && !(c->cfg.flags & GFS_F_DBG_NO_DEFER)) a.dbg |= 0x80u;   // team kernel: defer atomics by one trip
     a.bundle = c->bundle;
     a.n_nodes = (uint32_t)c->n_nodes;
 }

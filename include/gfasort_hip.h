@@ -106,6 +106,8 @@ typedef struct gfs_launch_config {
                                          a fused persistent launch is possible                        */
 #define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
 #define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
+#define GFS_F_DBG_NO_DEFER    0x400u  /* test hook: team kernels issue a trip's adds in that trip (one wave is then
+                                         an exact replay of the oracle's sequential mirror)                   */
 #define GFS_F_DBG_NO_ALIGN      0x1000u /* diagnostic: bundled sampler without line-aligned runs               */
 #define GFS_F_DBG_ALIGN_FIRST   0x2000u /* diagnostic: line-align only the first run of a bundle               */
 #define GFS_F_DBG_WIDE_INDEX 0x4000u  /* test hook: draw step indices with the u64 sampler that graphs of

@@ -863,3 +863,33 @@ def test_two_ranks_on_one_gpu_layout_2d():
     s1 = O.layout_stress(og, 2, lay1.coords, 100000)
     s2 = O.layout_stress(og, 2, c.reshape(-1, 2, 2), 100000)
     assert np.isfinite(c).all() and s1 < 0.1 * s0 and s2 < 0.1 * s0 and s2 < 2.0 * s1 + 1e-3, (s0, s1, s2)
+
+
+# ---- P0 for the team kernel: one wave replays the oracle's sequential mirror bit for bit ----------------------------
+@pytest.mark.parametrize("fused", [False, True])
+def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(fused):
+    """One wave of 64 streams, B = 64, atomics issued in the trip that computes them (GFS_F_DBG_NO_DEFER): trips run
+    one after another and the adds of a trip go to distinct nodes on a graph whose paths visit no node twice, so
+    the concurrent GPU trip equals the mirror's lane-by-lane application — positions must agree to the last bit.
+    Covers the arithmetic of the product's main kernel including line-aligned runs and merged short-jump trips."""
+    NO_DEFER = 0x400
+    g = G.synth_windows(40_000, 8, 20_000, 12)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 8
+    p.min_term_updates = 200_000
+    og, op = oracle_graph(g), oracle_params(p)
+    st_o = O.State(og, op, n_streams=64, bundle=64, node_slots=_node_slots(g))
+    x_ref = O.init_positions(og)
+    st_o.run(x_ref)
+    so = st_o.stats()
+    flags = hip.F_BUNDLE(64) | NO_DEFER | (0 if fused else hip.F_NO_FUSE)
+    ctx = hip.Context(g)
+    ctx.setup_1d(p, hip.make_config(n_streams=64, flags=flags))
+    ctx.upload(hip.init_positions(g))
+    ctx.run()
+    hst = ctx.stats()
+    x = ctx.download()
+    ctx.close()
+    assert hst.launches == (1 if fused else 9)
+    assert (hst.term_updates, hst.attempts) == (so.term_updates, so.attempts) and hst.term_updates == 9 * 200_000
+    assert np.array_equal(x.view(np.uint64), x_ref.view(np.uint64))
