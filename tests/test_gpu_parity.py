@@ -893,3 +893,28 @@ def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(fused):
     assert hst.launches == (1 if fused else 9)
     assert (hst.term_updates, hst.attempts) == (so.term_updates, so.attempts) and hst.term_updates == 9 * 200_000
     assert np.array_equal(x.view(np.uint64), x_ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_layout_team_kernel_single_wave_coords_equal_the_oracle_mirror(dims):
+    """The same for the layout kernels: one wave of sgdnd_team_kernel (end planes, one pair of end flips per run,
+    lane-regrouped adds) against the oracle's sequential mirror, coordinates bit for bit."""
+    g = G.synth_windows(40_000, 8, 20_000, 12)
+    p = P.LayoutSGDParams.from_graph(g, dims, 1)
+    p.iter_max = 6
+    p.min_term_updates = 150_000
+    og, op = oracle_graph(g), oracle_params(p)
+    c0 = gaussian_init(g, dims, 5)
+    c_ref = c0.copy()
+    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g))
+    st_o.run(c_ref)
+    so = st_o.stats()
+    ctx = hip.Context(g)
+    ctx.setup_nd(p, hip.make_config(n_streams=64, flags=hip.F_BUNDLE(64)))
+    ctx.upload(c0)
+    ctx.run()
+    hst = ctx.stats()
+    c = ctx.download()
+    ctx.close()
+    assert (hst.term_updates, hst.attempts) == (so.term_updates, so.attempts) and hst.term_updates == 7 * 150_000
+    assert np.array_equal(c.view(np.uint64), np.ascontiguousarray(c_ref).ravel().view(np.uint64))
