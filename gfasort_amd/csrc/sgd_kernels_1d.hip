@@ -91,23 +91,6 @@ struct TeamState {
     bool p1f = false, p2f = false; uint32_t p1s = 0, p2s = 0; double p1v = 0.0, p2v = 0.0;
 };
 
-// Short-jump trips of a 64-lane run (|jump| < 64).  Only the lanes of every other group of |jump| lanes act
-// (node-disjoint rule), and the partner of an acting lane is the step of a resting lane |jump| places on: both
-// sides of the trip touch the SAME lines.  Issued as two instructions they are two requests per line for half a
-// wave of updates, one straight after the other on the same lines — measured, these trips were 9 % of the trips
-// and 16 % of the time.  When the whole trip lies inside the path (no wrap, no mirrored jump) the +r of a term is
-// therefore handed to the resting lane that sits on its node, and ONE instruction carries every add of the trip;
-// only partners beyond the run's ends are added by a second, nearly empty one.  Returns the signed jump, or 0.
-template <int B>
-__device__ __forceinline__ int merged_trip_shift(uint32_t ok, uint32_t cnt, uint32_t ra0, uint32_t rb0) {
-    if (B != 64 || (ok & 3u) != 1u || cnt < 128u) return 0;
-    const int64_t s = (int64_t)rb0 - (int64_t)ra0;
-    if (s == 0 || s >= 64 || s <= -64) return 0;
-    if ((uint64_t)ra0 + 64u > cnt) return 0;                                           // the run would wrap
-    if (s > 0 ? (uint64_t)ra0 + 63u + (uint64_t)s > (uint64_t)cnt - 1u : (int64_t)ra0 + s < 0) return 0;
-    return (int)s;
-}
-
 // One SGD iteration of one wave: passes and trips until the wave's quota is filled.
 template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,

@@ -49,6 +49,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
         uint64_t first = bcast_first<B>(L, q); uint32_t cnt = bcast<B>(L.cnt, q);
         uint32_t flips = bcast<B>(lflips, q);
         bool valid = expand_run<B>(bcast<B>(L.ok, q), first, cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, sa, sb);
+        int mshift = merged_trip_shift<B>(bcast<B>(L.ok, q), cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q));   // see sgd_kernel_common.h
         uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, na = ra, nb = ra;
         if (valid) {
             ra = a.step_rec[sa]; rb = a.step_rec[sb];
@@ -56,12 +57,13 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
         }
 #pragma unroll 2
         for (int t = 0; t < B; ++t) {
-            uint64_t sa_n = 0, sb_n = 0, first_n = 0; uint32_t cnt_n = 0, flips_n = 0; bool valid_n = false;
+            uint64_t sa_n = 0, sb_n = 0, first_n = 0; uint32_t cnt_n = 0, flips_n = 0; bool valid_n = false; int mshift_n = 0;
             uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = ra_n, na_n = ra_n, nb_n = ra_n;
             if (t + 1 < B) {
                 const int ll = (t + 1) * RUNS + q;
                 first_n = bcast_first<B>(L, ll); cnt_n = bcast<B>(L.cnt, ll); flips_n = bcast<B>(lflips, ll);
                 valid_n = expand_run<B>(bcast<B>(L.ok, ll), first_n, cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa_n, sb_n);
+                mshift_n = merged_trip_shift<B>(bcast<B>(L.ok, ll), cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll));
                 if (valid_n) {
                     ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n];
                     na_n = a.step_rec[sa_n + 1u < a.n_steps ? sa_n + 1u : sa_n];
@@ -144,24 +146,52 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                 // 64/P neighbouring nodes = 512 (384 for D=3) contiguous bytes = 8-9 (6-7) requests.
                 // Wave-uniform control flow: all lanes take part in the shuffles.
                 constexpr int P = D <= 2 ? 2 : 4;
+                // the two adds of this lane: A = -r to end i, B = +r to end j (:1143-1149)
+                double vA[D], vB[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { vA[k] = -upd_r[k]; vB[k] = upd_r[k]; }
+                unsigned long long pA = (unsigned long long)upd_ci, pB = (unsigned long long)upd_cj;
+                int fA = (int)upd_i, fB = (int)upd_j;
+                if (B == 64 && mshift != 0) {
+                    // merged short-jump trip (sgd_kernel_common.h merged_trip_shift): the resting lane that sits on the
+                    // partner step of an acting lane issues that lane's +r, so that one instruction carries the trip
+                    const int z = mshift < 0 ? -mshift : mshift;
+                    const int src = lane - mshift;
+                    const int srcc = src < 0 ? 0 : (src > 63 ? 63 : src);
+                    const unsigned long long pjs = __shfl(pB, srcc, 64);
+                    const int fjs = __shfl(fB, srcc, 64);
+                    double rs[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) rs[k] = __shfl(upd_r[k], srcc, 64);
+                    const bool resting = (((uint32_t)lane / (uint32_t)z) & 1u) != 0u;
+                    if (resting && src >= 0 && src < 64 && fjs) {
+                        pA = pjs; fA = 1;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) vA[k] = rs[k];
+                    }
+                    const int dst = lane + mshift;
+                    fB = fB && (dst < 0 || dst > 63);                                  // partner beyond the run: add it myself
+                }
                 const int d = lane & (P - 1);
 #pragma unroll
                 for (int pass = 0; pass < P; ++pass) {
                     const int m = pass * (64 / P) + lane / P;
-                    double v = 0.0;
+                    double va = 0.0, vb = 0.0;
 #pragma unroll
-                    for (int k = 0; k < D; ++k) { const double rk = __shfl(upd_r[k], m, 64); if (k == d) v = rk; }
-                    const unsigned long long pi = __shfl((unsigned long long)upd_ci, m, 64);
-                    const unsigned long long pj = __shfl((unsigned long long)upd_cj, m, 64);
-                    const int fi = __shfl((int)upd_i, m, 64), fj = __shfl((int)upd_j, m, 64);
+                    for (int k = 0; k < D; ++k) {
+                        const double ak = __shfl(vA[k], m, 64), bk = __shfl(vB[k], m, 64);
+                        if (k == d) { va = ak; vb = bk; }
+                    }
+                    const unsigned long long pa = __shfl(pA, m, 64), pb = __shfl(pB, m, 64);
+                    const int fa = __shfl(fA, m, 64), fb = __shfl(fB, m, 64);
                     if (d < D) {
-                        if (fi) add_pos(reinterpret_cast<double *>(pi) + d, -v);
-                        if (fj) add_pos(reinterpret_cast<double *>(pj) + d, v);
+                        if (fa) add_pos(reinterpret_cast<double *>(pa) + d, va);
+                        if (fb) add_pos(reinterpret_cast<double *>(pb) + d, vb);
                     }
                 }
             }
             if (wave_done >= wave_quota) break;
-            ra = ra_n; rb = rb_n; na = na_n; nb = nb_n; sa = sa_n; sb = sb_n; valid = valid_n; first = first_n; cnt = cnt_n; flips = flips_n;
+            ra = ra_n; rb = rb_n; na = na_n; nb = nb_n; sa = sa_n; sb = sb_n; valid = valid_n; first = first_n; cnt = cnt_n; flips = flips_n; mshift = mshift_n;
         }
     }
     a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;
