@@ -325,11 +325,12 @@ static int upload_zeta_table(gfs_ctx *c, const gfs_sgd_params *p, const double *
 
 // Streams per launch when the caller leaves it to the library.
 static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
-    // 768 lanes per CU (3 waves per SIMD): the measured optimum on MI355X for the team kernels, fused or
-    // one launch per iteration, 1D and nD (profiles/r01/sweep_streams_final.log; reference streams are flat
-    // within 5 % from 512 up).  Each wave is a serial chain of memory round trips, so more chains raise
-    // throughput until the memory-side atomic units saturate; past ~1024 lanes per CU nothing is gained.
-    const uint64_t chip = (uint64_t)c->cu_count * 768;
+    // 976 lanes per CU (just under 4 waves per SIMD; 249 856 on MI355X): each wave is a serial chain of memory round
+    // trips, so more chains raise throughput until the memory-side atomic units saturate.  Measured with the final
+    // kernels (profiles/r01/sweep_streams_final.log, defer_probe.log): C3 69.1 / 78.7 / 80.2 G updates/s at 512 / 768 /
+    // 976 lanes per CU, 600k nodes 66.7 / 75.6 / 77.7, C4 layout flat from 768 up; reference streams are flat within
+    // 5 % from 512 up.  (976 rather than 1024 keeps 4*streams <= 1e6 nodes, the deferral condition, on C3-sized graphs.)
+    const uint64_t chip = (uint64_t)c->cu_count * 976;
     // keep >= 8 updates per stream per batch on small graphs
     const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
     // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight
