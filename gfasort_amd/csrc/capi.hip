@@ -33,7 +33,7 @@ hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_ste
                                      int *bad_out);
 hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
                                    const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
-                                   uint64_t n_steps, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len);
+                                   uint64_t n_steps, uint64_t n_nodes, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len);
 hipError_t sort_order_device(const double *d_x_layout, const uint32_t *d_perm, uint64_t n, uint64_t stride_doubles,
                              void *d_tmp, uint32_t **d_order_out);
 hipError_t launch_merge_prepare(const double *x, const double *x_prev, float *buf, uint64_t n, hipStream_t st);
@@ -472,7 +472,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     *out = nullptr;
     if (g->n_steps > (1ull << 40)) return fail(GFS_E_UNSUPPORTED, "more than 2^40 path steps");
     if (g->n_nodes > 0x7FFFFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^31-1 nodes");
-    if (g->n_paths > 0x7FFFFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^31-1 paths");
+    if (g->n_paths > 0x3FFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^22-1 paths (the step records keep 22 bits for the path)");
     if (g->n_steps && (!g->step_node || !g->step_is_rev)) return fail(GFS_E_ARG, "null step arrays");
     if (!g->path_first_step) return fail(GFS_E_ARG, "null path_first_step");
     if (g->n_nodes && !g->node_len) return fail(GFS_E_ARG, "null node_len");
@@ -581,7 +581,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
 
         GFS_TRY("hipMemcpy path_first", hipMemcpy(d_first, g->path_first_step, (P + 1) * 8, hipMemcpyHostToDevice));
         lap("upload");
-        GFS_TRY("build_path_index", gfs::build_path_index_device(d_step_node, d_rev, c->d_node_len, c->d_perm, d_first, (uint32_t)P, S,
+        GFS_TRY("build_path_index", gfs::build_path_index_device(d_step_node, d_rev, c->d_node_len, c->d_perm, d_first, (uint32_t)P, S, N,
                                                                   d_tmp, c->d_step_rec, c->d_path_len));
     }
 #undef GFS_TRY
@@ -701,6 +701,11 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     if (4 * c->n_streams <= c->n_nodes && !(c->cfg.flags & GFS_F_DBG_NO_DEFER)) a.dbg |= 0x80u;   // team kernel: defer atomics by one trip
     a.bundle = c->bundle;
     a.n_nodes = (uint32_t)c->n_nodes;
+    {   // crowding onset (sgd_device.h crowd_shift): four times the concurrency of an average node
+        const uint64_t per = c->n_steps / std::max<uint64_t>(2 * c->n_streams, 1);
+        int lg = 0; while ((per >> (lg + 1)) != 0) ++lg;               // floor(log2(max(per, 1)))
+        a.kshift = lg + 2; a._pad3 = 0;
+    }
 }
 
 static int next_event_pair(gfs_ctx *c, std::pair<hipEvent_t, hipEvent_t> *&ev) {

@@ -27,10 +27,30 @@ struct StepLen {
     }
 };
 
-// rec[s] = { internal node slot | NO_NODE, path | rev<<31, pos lo, pos hi } with pos = scan[s] - scan[first(path)]
+// Crowding statistics of the nodes (sgd_device.h crowd_shift): cnt[n] = steps on node n; rep[n] = the most visits
+// to n within any 64 consecutive steps of one path (a step counts its node's earlier visits among the 63 steps
+// before it, not looking across the start of its path).
+__global__ void node_stats_kernel(const uint32_t *step_node, const uint64_t *path_first, uint32_t n_paths, uint64_t n_steps,
+                                  uint32_t *cnt, uint32_t *rep) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_steps; s += stride) {
+        const uint32_t n = step_node[s];
+        if (n == 0xFFFFFFFFu) continue;
+        atomicAdd(&cnt[n], 1u);
+        uint32_t lo = 0, hi = n_paths;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (path_first[mid] <= s) lo = mid; else hi = mid; }
+        const uint64_t begin = path_first[lo], from = s - begin > 63 ? s - 63 : begin;
+        uint32_t c = 1;
+        for (uint64_t t = from; t < s; ++t) c += step_node[t] == n;
+        if (c > 1 && rep[n] < c) atomicMax(&rep[n], c);
+    }
+}
+__device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t v) { return v <= 1 ? 0u : 32u - (uint32_t)__clz((int)(v - 1)); }
+
+// rec[s] = { internal node slot | NO_NODE, path | a<<22 | b<<28 | rev<<31, pos lo, pos hi } with pos = scan[s] - scan[first(path)]
 __global__ void fill_records_kernel(const uint32_t *step_node, const uint8_t *step_is_rev, const uint32_t *perm,
                                     const uint64_t *scan, const uint64_t *path_first, uint32_t n_paths,
-                                    uint4 *rec, uint64_t n_steps) {
+                                    const uint32_t *cnt, const uint32_t *rep, uint4 *rec, uint64_t n_steps) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_steps; s += stride) {
         // path of step s: last p with path_first[p] <= s (empty paths share a boundary: take the last)
@@ -40,7 +60,12 @@ __global__ void fill_records_kernel(const uint32_t *step_node, const uint8_t *st
         const uint32_t n = step_node[s];
         uint4 r;
         r.x = n == 0xFFFFFFFFu ? 0xFFFFFFFFu : perm[n];
-        r.y = lo | ((uint32_t)(step_is_rev[s] & 1) << 31);
+        uint32_t crowd = 0;
+        if (n != 0xFFFFFFFFu) {
+            const uint32_t a = ceil_log2_u32(cnt[n]), b = ceil_log2_u32(rep[n]);
+            crowd = ((a > 63u ? 63u : a) << 22) | ((b > 7u ? 7u : b) << 28);
+        }
+        r.y = lo | crowd | ((uint32_t)(step_is_rev[s] & 1) << 31);
         r.z = (uint32_t)pos; r.w = (uint32_t)(pos >> 32);
         rec[s] = r;
     }
@@ -54,7 +79,7 @@ __global__ void path_len_kernel(const uint64_t *scan, const uint64_t *path_first
 // All pointers are device pointers; tmp holds (n_steps+1) u64 (the scan).  Synchronous.
 hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
                                    const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
-                                   uint64_t n_steps, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len) {
+                                   uint64_t n_steps, uint64_t n_nodes, uint64_t *d_tmp, uint4 *d_rec, uint64_t *d_path_len) {
     uint64_t *d_scan = d_tmp;
     const unsigned blocks = 2048;
     auto lens = rocprim::make_transform_iterator(rocprim::counting_iterator<uint64_t>(0), StepLen{d_step_node, d_node_len, n_steps});
@@ -66,14 +91,20 @@ hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d
     if ((e = hipMalloc(&d_scan_tmp, tmp_bytes ? tmp_bytes : 8)) != hipSuccess) return e;
     e = rocprim::exclusive_scan(d_scan_tmp, tmp_bytes, lens, d_scan, (uint64_t)0, (size_t)(n_steps + 1),
                                 rocprim::plus<uint64_t>(), 0);
+    uint32_t *d_cnt = nullptr, *d_rep = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&d_cnt, (n_nodes ? n_nodes : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_rep, (n_nodes ? n_nodes : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(d_cnt, 0, (n_nodes ? n_nodes : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(d_rep, 0, (n_nodes ? n_nodes : 1) * sizeof(uint32_t));
     if (e == hipSuccess) {
+        hipLaunchKernelGGL(node_stats_kernel, dim3(4096), dim3(256), 0, 0, d_step_node, d_path_first, n_paths, n_steps, d_cnt, d_rep);
         hipLaunchKernelGGL(fill_records_kernel, dim3(blocks), dim3(256), 0, 0, d_step_node, d_step_is_rev, d_perm, d_scan,
-                           d_path_first, n_paths, d_rec, n_steps);
+                           d_path_first, n_paths, d_cnt, d_rep, d_rec, n_steps);
         hipLaunchKernelGGL(path_len_kernel, dim3((n_paths + 255) / 256), dim3(256), 0, 0, d_scan, d_path_first, d_path_len, n_paths);
         e = hipGetLastError();
     }
     hipError_t e2 = hipDeviceSynchronize();
-    (void)hipFree(d_scan_tmp);
+    (void)hipFree(d_scan_tmp); (void)hipFree(d_cnt); (void)hipFree(d_rep);
     return e != hipSuccess ? e : e2;
 }
 

@@ -83,7 +83,7 @@ struct IterConsts {
 };
 
 // device mirror of PathIndex (sgd.rs:14-31), flattened:
-//   step_rec[s]  = { node dense idx | NO_NODE, path id | rev<<31, pos lo, pos hi }  (16 B)
+//   step_rec[s]  = { node slot | NO_NODE, path id (22 bits) | crowding a<<22 b<<28 | rev<<31, pos lo, pos hi }  (16 B)
 //   path_rec[p]  = { first_step lo, step_count, (2^32-count) mod count, first_step hi } (16 B)
 struct KArgs {
     const uint4    *step_rec;
@@ -106,6 +106,7 @@ struct KArgs {
     uint32_t space, space_max, space_q;
     uint32_t dbg;                  // diagnostic ablation bits (GFS_F_DBG_* >> 8), 0 in production
     uint32_t bundle, n_nodes;      // lanes per sampling bundle (1 = reference streams); node count (nD planes)
+    int32_t  kshift, _pad3;        // crowding: floor(log2(n_steps / (2 * n_streams))) + 2, see crowd_shift()
     IterConsts it;
 };
 
@@ -116,6 +117,31 @@ __device__ __forceinline__ uint64_t sample_step(const KArgs &a, Rng &rng) {
     return rng.uniform64(a.n_steps, a.steps_thresh);
 }
 __device__ __forceinline__ uint64_t path_first(const uint4 &pr) { return ((uint64_t)pr.w << 32) | pr.x; }
+constexpr uint32_t PATH_MASK = 0x3FFFFFu;                // step_rec.y bits 0..21: path id
+__device__ __forceinline__ uint32_t rec_path(const uint4 &r) { return r.y & PATH_MASK; }
+
+// Crowded nodes.  The kernels run ~2.5e5 terms at once where the reference runs <= 64, and a term corrects its two
+// nodes from positions read before the other in-flight terms landed.  For an ordinary node that is at most one or two
+// concurrent corrections (the streams-per-node bound, capi.hip); but a node that carries a large share of all steps
+// (a hub), or that a path steps on many times in a row (a tandem repeat: a run of 64 consecutive steps then hits it
+// with many lanes of the SAME trip), receives dozens of full corrections of the same error at once and the positions
+// blow up (measured: NaN on graphs with 40-fold self-loops, profiles/r01/repeat_probe.log).  Every step record
+// therefore carries two small exponents of its node, computed when the index is built (index_kernels.hip):
+//   a = ceil(log2(steps on the node)),  b = ceil(log2(most visits within any 64 consecutive steps of a path)),
+// and a term's mu is scaled by 2^-k, k = max over its two nodes of max(b, a - kshift): c concurrent corrections of
+// 1/c-th size add up to about one.  kshift = floor(log2(n_steps / (2 n_streams))) + 2 puts the onset at four times
+// the concurrency an average node sees, so ordinary graphs (every test graph of the parity ladder) have k = 0
+// everywhere and are bit-for-bit unaffected.  The reference has no such rule; it has no such concurrency either.
+template <bool RUNS>   // RUNS: the lanes of a wave take consecutive steps (team kernels), so tandem repeats matter
+__device__ __forceinline__ int crowd_shift(const KArgs &a, const uint4 &ra, const uint4 &rb) {
+    const int aa = (int)((ra.y >> 22) & 63u) - a.kshift, ab = (int)((rb.y >> 22) & 63u) - a.kshift;
+    const int ba = RUNS ? (int)((ra.y >> 28) & 7u) : 0, bb = RUNS ? (int)((rb.y >> 28) & 7u) : 0;
+    int k = aa > ab ? aa : ab;
+    const int b = ba > bb ? ba : bb;
+    k = k > b ? k : b;
+    return k > 0 ? k : 0;
+}
+__device__ __forceinline__ double crowd_scale(double mu, int k) { return k ? ldexp(mu, -k) : mu; }
 
 // nD coordinates on the device: two END PLANES, coords[end][slot][dim].  (The ABI and Layout.coords,
 // layout.rs:14, are [node][end][dim]; upload/download translate.)  A run of consecutive nodes taking the
@@ -156,7 +182,7 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
                                             uint32_t &cnt_out, uint32_t &path_out) {
     const uint64_t step_idx = sample_step(a, rng);                                     // :444
     ra = a.step_rec[step_idx];
-    uint32_t path = ra.y & 0x7FFFFFFFu;                                                // :445
+    uint32_t path = rec_path(ra);                                                      // :445
     uint4 pr = path_tab[path];
     const uint64_t first = path_first(pr); const uint32_t cnt = pr.y;                  // :446
     if (cnt == 1u) return false;                                                       // :448
@@ -221,7 +247,7 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
     Leader L;
     const uint64_t s0 = sample_step(a, rng);                                           // sgd.rs:444
     const uint4 r0 = a.step_rec[s0];
-    const uint4 pr = path_tab[r0.y & 0x7FFFFFFFu];                                     // :445-446
+    const uint4 pr = path_tab[rec_path(r0)];                                           // :445-446
     L.first_lo = pr.x; L.first_hi = pr.w; L.cnt = pr.y;
     L.ra0 = (uint32_t)(s0 - path_first(pr)); L.rb0 = L.ra0;                            // :452-453
     L.ok = 0;

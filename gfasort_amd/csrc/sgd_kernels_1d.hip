@@ -31,7 +31,7 @@ __global__ void sgd1d_kernel(const KArgs a) {
             if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) continue;
             double term_dist = fabs(rec_pos(ra) - rec_pos(rb));                        // sgd.rs:513
             if (term_dist == 0.0) continue;                                            // :514
-            double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                       // :518-520
+            double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd_shift<false>(a, ra, rb));                       // :518-520
             const uint32_t i = ra.x, j = rb.x;
             if (i == 0xFFFFFFFFu || j == 0xFFFFFFFFu) continue;                        // :525-538
             double dx;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
             }
             double r_x = 0.0;
             if (valid) {
-                double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                   // :518-520
+                double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd_shift<true>(a, ra, rb));                   // :518-520
                 double dx = xi - xj;                                                   // :543
                 if (dx == 0.0) dx = 1e-9;                                              // :546-548
                 double mag = fabs(dx);                                                 // :551

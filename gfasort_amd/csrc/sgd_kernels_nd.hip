@@ -48,7 +48,7 @@ __global__ void sgdnd_kernel(const KArgs a) {
             if (ob) { pos_b += len_j; ob = !rev_j; } else { ob = rev_j; }              // :1072-1077
             double term_dist = fabs(pos_a - pos_b);                                    // :1080
             if (term_dist == 0.0) continue;                                            // :1081
-            double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                       // :1085-1086
+            double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd_shift<false>(a, ra, rb));                       // :1085-1086
             if (ra.x == 0xFFFFFFFFu || rb.x == 0xFFFFFFFFu) continue;                  // :1089-1096
             const uint64_t idx_i = (uint64_t)ra.x * 2u + (oa ? 1u : 0u);               // :1099-1103
             const uint64_t idx_j = (uint64_t)rb.x * 2u + (ob ? 1u : 0u);

@@ -76,7 +76,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
             bool oa = false, ob = false;
             if (valid) {
                 const uint64_t last_step = first + cnt - 1u;
-                const uint64_t plen = a.path_len[ra.y & 0x7FFFFFFFu];
+                const uint64_t plen = a.path_len[rec_path(ra)];
                 const uint64_t pa = ((uint64_t)ra.w << 32) | ra.z, pb = ((uint64_t)rb.w << 32) | rb.z;
                 const uint64_t ea = sa == last_step ? plen : (((uint64_t)na.w << 32) | na.z);
                 const uint64_t eb = sb == last_step ? plen : (((uint64_t)nb.w << 32) | nb.z);
@@ -104,7 +104,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
 #pragma unroll
             for (int d = 0; d < D; ++d) upd_r[d] = 0.0;
             if (valid) {
-                double mu = fmin(a.it.eta * (1.0 / term_dist), 1.0);                   // :1085-1086
+                double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd_shift<true>(a, ra, rb));                   // :1085-1086
                 double *ci = coord_ptr<D>(a, ra.x, oa), *cj = coord_ptr<D>(a, rb.x, ob);
                 double deltas[D];
                 double mag_sq = 0.0;

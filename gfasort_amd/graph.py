@@ -288,3 +288,27 @@ def synth_to_gfa_text(g: FlatGraph) -> str:
         ids = g.step_node_id[first[p]:first[p + 1]]
         out.append(f"P\t{name}\t{','.join(f'{int(i)}+' for i in ids)}\t*")
     return "\n".join(out) + "\n"
+
+
+def synth_repeats(n: int, n_paths: int, period: int, max_copies: int, every: int, seed: int) -> FlatGraph:
+    """Chain of n nodes in which every `every`-th position starts a block of `period` nodes that each path
+    traverses 1..max_copies times in a row (copy-number variation / tandem repeats; period 1 = self-loops).
+    Consecutive path steps then revisit the same nodes, which a linear chain never does."""
+    rng = np.random.default_rng(seed)
+    node_len = rng.integers(1, 17, n).astype(np.uint32)
+    steps, first = [], [0]
+    for _ in range(n_paths):
+        k = 0
+        while k < n:
+            if k % every == 0 and k + period <= n:
+                c = int(rng.integers(1, max_copies + 1))
+                for _ in range(c):
+                    steps.extend(range(k, k + period))
+                k += period
+            else:
+                steps.append(k)
+                k += 1
+        first.append(len(steps))
+    return FlatGraph(node_len=node_len, step_node=np.array(steps, dtype=np.uint32),
+                     step_is_rev=np.zeros(len(steps), dtype=np.uint8), path_first_step=np.array(first, dtype=np.uint64),
+                     node_ids=np.arange(1, n + 1, dtype=np.uint64), path_names=[f"p{i}" for i in range(n_paths)])

@@ -918,3 +918,23 @@ def test_layout_team_kernel_single_wave_coords_equal_the_oracle_mirror(dims):
     ctx.close()
     assert (hst.term_updates, hst.attempts) == (so.term_updates, so.attempts) and hst.term_updates == 7 * 150_000
     assert np.array_equal(c.view(np.uint64), np.ascontiguousarray(c_ref).ravel().view(np.uint64))
+
+
+# ---- crowded nodes: tandem repeats and hubs (sgd_device.h crowd_shift) ---------------------------------------------
+@pytest.mark.parametrize("period,copies,every", [(1, 40, 500), (5, 20, 300), (1, 200, 2000)])
+def test_tandem_repeats_and_hub_nodes_stay_stable(period, copies, every):
+    """Paths that step on the same node(s) many times in a row: a run of consecutive steps then hits one node with
+    many lanes of the same trip, and a node with hundreds of steps is hit by many waves at once.  Without the
+    crowding exponents every mode ended in NaN here; with them the result stays within reach of the CPU oracle's."""
+    g = G.synth_repeats(60_000, 16, period, copies, every, 3)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    og = oracle_graph(g)
+    x_ref = O.init_positions(og)
+    s0 = O.stress_1d(og, x_ref, 100000)
+    O.sgd_1d(og, oracle_params(p), x_ref, n_streams=8)
+    s_ref = O.stress_1d(og, x_ref, 100000)
+    for bundle in (1, 0):
+        rc, x, st = hip.path_linear_sgd_raw(g, p, cfg=hip.make_config(flags=hip.F_BUNDLE(bundle)))
+        assert rc == 0 and np.isfinite(x).all()
+        s = O.stress_1d(og, x, 100000)
+        assert s < 0.7 * s0 and s < 2.0 * s_ref + 1e-3, (bundle, st.bundle, s0, s_ref, s)
