@@ -44,6 +44,8 @@ typedef struct gfs_graph_view {
     uint64_t        n_nodes;          /* graph.node_count()                       sgd.rs:241 */
     uint64_t        n_steps;          /* PathIndex::get_total_steps()             sgd.rs:73  */
     uint64_t        n_paths;          /* PathIndex::num_paths()                   sgd.rs:101 */
+                                       /* limits of the device mirror: n_nodes < 2^31, n_paths < 2^22,
+                                          n_steps <= 2^40, < 2^32 steps per path (GFS_E_UNSUPPORTED beyond) */
     const uint32_t *node_len;         /* [n_nodes]  sequence.len() by dense index            */
     const uint32_t *step_node;        /* [n_steps]  dense index of the step's node, or
                                          GFS_NO_NODE when the id is absent from the graph
