@@ -938,3 +938,16 @@ def test_tandem_repeats_and_hub_nodes_stay_stable(period, copies, every):
         assert rc == 0 and np.isfinite(x).all()
         s = O.stress_1d(og, x, 100000)
         assert s < 0.7 * s0 and s < 2.0 * s_ref + 1e-3, (bundle, st.bundle, s0, s_ref, s)
+
+
+def test_layout_kernels_stay_finite_on_tandem_repeats():
+    from gfasort_amd import sgd as S
+    g = G.synth_repeats(40_000, 16, 1, 40, 500, 5)
+    p = P.LayoutSGDParams.from_graph(g, 2, 1)
+    og = oracle_graph(g)
+    c0 = S.default_layout_init(g, 2, p.seed)
+    s0 = O.layout_stress(og, 2, c0, 50000)
+    for bundle in (1, 0):
+        rc, c, st = hip.path_linear_sgd_layout_raw(g, p, c0.copy(), cfg=hip.make_config(flags=hip.F_BUNDLE(bundle)))
+        assert rc == 0 and np.isfinite(c).all()
+        assert O.layout_stress(og, 2, c.reshape(-1, 2, 2), 50000) < 0.5 * s0
