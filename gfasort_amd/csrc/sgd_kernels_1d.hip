@@ -76,7 +76,9 @@ __global__ void sgd1d_kernel(const KArgs a) {
 //            number of nodes (4*n_streams <= n_nodes) — on small graphs with many streams the
 //            extra staleness pushed the concurrent corrections per node past stability.
 // The quota is per WAVE with a rank cut-off in the last trip: an iteration performs exactly its
-// number of updates; leaders left over when the quota fills are discarded.
+// number of updates; the trips of a pass left over when the quota fills serve the next iteration
+// (TeamState).  Runs are line-aligned (sgd_device.h sample_leader) and short-jump trips issue all
+// their adds in one instruction (sgd_kernel_common.h merged_trip_shift).
 // ------------------------------------------------------------------------------------------
 // Per-wave state that survives from one iteration to the next inside a launch.
 struct TeamState {
