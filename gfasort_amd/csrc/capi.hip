@@ -251,6 +251,7 @@ struct gfs_ctx {
     uint64_t n_streams = 0, quota_total = 0;
     uint32_t block = 256;
     uint32_t bundle = 1;               // lanes per sampling bundle actually used (1 = reference streams)
+    uint32_t chain = 1;                // longest run in trips (sgd_device.h run_trips); 1 = a run is one trip
     bool lds_tables = true, atomic_loads = true;
     size_t lds_bytes = 0;
     // timing
@@ -372,6 +373,13 @@ static int choose_bundle(gfs_ctx *c, int dims) {
         }
     }
     c->bundle = b;
+    // Long runs (sgd_device.h run_trips): flags bits 24..31, 0 = auto.  Only the 1D team kernel at B = 64 chains trips;
+    // auto = 16 trips (runs of 1024 steps, adapted per path): the error profile over path distances of the oracle's
+    // mirror is then within a few % of reference streams on bubble graphs of 131k-2M nodes (profiles/r02).
+    uint32_t k = (c->cfg.flags >> 24) & 0xFFu;
+    if (k > 64 || (k & (k - 1))) return fail(GFS_E_ARG, "GFS_F_CHAIN: the run length in trips must be a power of two <= 64");
+    if (k == 0) k = 16;
+    c->chain = (b == 64 && dims == 0) ? k : 1;
     return GFS_OK;
 }
 
@@ -388,7 +396,17 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     c->params = *p;
     c->cfg = cfg ? *cfg : gfs_launch_config{};
     c->dims = dims;
-    if (!c->valid_paths || c->n_nodes == 0) { c->configured = true; return GFS_NOTHING_TO_DO; }
+    c->x_len = 0;
+    if (c->n_nodes == 0) { c->configured = true; return GFS_NOTHING_TO_DO; }
+
+    // positions.  A context with nothing to do (no path of more than one step: sgd.rs:250-261 returns before any
+    // update) still owns a full-length position replica: a multi-GPU rank whose shard holds no such path must be able to
+    // upload, bind, merge and download like its peers — its contribution to every merge is a zero delta of the same size.
+    c->x_len = dims ? c->n_nodes * 2 * (uint64_t)dims : c->n_nodes;
+    HIPCHK(hipMalloc(&c->d_x, c->x_len * 8));
+    HIPCHK(hipMemset(c->d_x, 0, c->x_len * 8));
+    c->x_owned = true;
+    if (!c->valid_paths) { c->configured = true; return GFS_NOTHING_TO_DO; }
 
     // eta schedule and zeta table (host, bit-exact) unless supplied
     c->etas.resize(p->iter_max + 1);
@@ -396,12 +414,6 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     else gfs_sgd_schedule(p, c->etas.data());
     rc = upload_zeta_table(c, p, zetas);
     if (rc) return rc;
-
-    // positions
-    c->x_len = dims ? c->n_nodes * 2 * (uint64_t)dims : c->n_nodes;
-    HIPCHK(hipMalloc(&c->d_x, c->x_len * 8));
-    HIPCHK(hipMemset(c->d_x, 0, c->x_len * 8));
-    c->x_owned = true;
 
     // launch shape
     c->quota_total = c->cfg.term_updates_per_iteration ? c->cfg.term_updates_per_iteration : p->min_term_updates;
@@ -698,13 +710,15 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
     a.dbg = (c->cfg.flags >> 8) & 0x7Fu;             // bit 0x40 = GFS_F_DBG_WIDE_INDEX >> 8
+    if (c->cfg.flags & 0x8000u) a.dbg |= 0x100u;      // experiment: wait for a colour's adds before the next colour reads
     if (4 * c->n_streams <= c->n_nodes && !(c->cfg.flags & GFS_F_DBG_NO_DEFER)) a.dbg |= 0x80u;   // team kernel: defer atomics by one trip
     a.bundle = c->bundle;
+    a.chain = c->chain;
     a.n_nodes = (uint32_t)c->n_nodes;
     {   // crowding onset (sgd_device.h crowd_shift): four times the concurrency of an average node
         const uint64_t per = c->n_steps / std::max<uint64_t>(2 * c->n_streams, 1);
         int lg = 0; while ((per >> (lg + 1)) != 0) ++lg;               // floor(log2(max(per, 1)))
-        a.kshift = lg + 2; a._pad3 = 0;
+        a.kshift = lg + 2;
     }
 }
 
@@ -835,7 +849,7 @@ int gfs_ctx_stats(gfs_ctx *c, gfs_stats *out) {
     std::vector<unsigned long long> cnt(kCounterBytes / 8);
     HIPCHK(hipMemcpy(cnt.data(), c->d_counters, kCounterBytes, hipMemcpyDeviceToHost));
     for (size_t s = 0; s < cnt.size(); s += 8) { out->term_updates += cnt[s]; out->attempts += cnt[s + 1]; }
-    out->iterations = c->iterations; out->n_streams = c->n_streams; out->bundle = c->bundle;
+    out->iterations = c->iterations; out->n_streams = c->n_streams; out->bundle = c->bundle; out->run_trips = c->chain;
     double ms = c->kernel_ms_harvested;
     for (size_t k = 0; k < c->events_used; ++k) {
         float t = 0.f;

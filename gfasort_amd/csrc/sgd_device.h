@@ -106,7 +106,8 @@ struct KArgs {
     uint32_t space, space_max, space_q;
     uint32_t dbg;                  // diagnostic ablation bits (GFS_F_DBG_* >> 8), 0 in production
     uint32_t bundle, n_nodes;      // lanes per sampling bundle (1 = reference streams); node count (nD planes)
-    int32_t  kshift, _pad3;        // crowding: floor(log2(n_steps / (2 * n_streams))) + 2, see crowd_shift()
+    int32_t  kshift;               // crowding: floor(log2(n_steps / (2 * n_streams))) + 2, see crowd_shift()
+    uint32_t chain;                // longest run in trips (power of two; 1 = a run is one trip), see run_trips()
     IterConsts it;
 };
 
@@ -225,8 +226,8 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
 //     a path end samples into the path in the reference too) and is rejected if that fails as
 //     well — never clamped: clamping would pile several lanes onto the path's last step;
 //     lane 0 is the leader's own term, unchanged;
-//   * when |jump| < B the run's terms would chain through shared nodes (a_{l+z} = b_l); only
-//     lanes with floor(l/z) even act, which makes the acting terms node-disjoint;
+//   * when |jump| < B the run's terms would chain through shared nodes (a_{l+z} = b_l); the run is
+//     executed as two node-disjoint trips (colours): lanes with floor(l/z) even, then the odd ones;
 //   * paths shorter than 2B steps are handled by lane 0 alone.
 // Every acting lane's term has the reference's marginal distribution up to path-end effects of
 // O(B/cnt); what changes is the correlation BETWEEN concurrent terms.  The pay-off is in the
@@ -241,6 +242,23 @@ struct Leader {            // one sampled leader term (per lane, registers)
     uint32_t ok;           // bit 0: 0 = the reference `continue`d (cnt == 1 or rank_a == rank_b);
                            // bit 1: both runs line-aligned, bits 2..4: lane rotation r (sample_leader)
 };
+
+// LONG RUNS.  A leader is expanded not over one trip but over K consecutive trips of its wave: trip `seg` takes the
+// steps seg*B .. seg*B+B-1 further along the path, all with the leader's jump, so a run is K*B consecutive steps.
+// Why: every term of a run moves its two nodes by about the same amount (same path, same interval: the same
+// disagreement between this path's distance and the layout's), i.e. a run shifts two BLOCKS rigidly and leaves a
+// step at the block's edges.  With B-step blocks those edges are dense, and nothing repairs them once the schedule
+// has cooled (sgd.rs:456: in the cooling half only jumps of 1, 2 and near-uniform long jumps are drawn), which showed
+// as +30 % relative error at path distances around B on large bubble graphs.  Longer blocks have proportionally fewer
+// edges: with K*B = 1024 the error profile over all path distances is within a few % of the reference's independent
+// terms, and below it at short distances (oracle mirror, profiles/r02/long_runs_mirror.log).  K adapts to the
+// leader's path: the largest power of two <= a.chain with K*B <= cnt/4, so short paths keep short runs.
+__device__ __forceinline__ uint32_t run_trips(uint32_t chain, uint32_t bundle, uint32_t cnt) {
+    const uint32_t room = cnt / (4u * bundle);
+    if (room < 2u || chain < 2u) return 1u;
+    const uint32_t p2 = 1u << (31 - __clz((int)room));
+    return p2 < chain ? p2 : chain;
+}
 
 template <bool LDS_TABLES>
 __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng) {
@@ -284,13 +302,14 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
         // C3: 0.30 -> 0.26 atomic requests per update, 68 -> 74 G updates/s.
         const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0;
         const int64_t Bn = (int64_t)a.bundle;
+        const int64_t Rn = Bn * (int64_t)run_trips(a.chain, a.bundle, L.cnt);         // steps of the whole run
         if (jump >= Bn + 8 || jump <= -(Bn + 8)) {
             const int64_t A = a.bundle < 8u ? (int64_t)a.bundle : 8;               // runs shorter than a line: align to the run length
             const uint32_t sh = r0.x & (uint32_t)(A - 1);
             if (L.ra0 >= sh) {
                 const int64_t na = (int64_t)L.ra0 - (int64_t)sh;
                 const int64_t r = ((jump % A) + A) % A, zp = jump - r, nb = na + zp;
-                if (!(a.dbg & 0x20u) && na + Bn <= (int64_t)L.cnt && nb >= 0 && nb + Bn <= (int64_t)L.cnt && (zp >= Bn || zp <= -Bn)) {
+                if (!(a.dbg & 0x20u) && na + Rn <= (int64_t)L.cnt && nb >= 0 && nb + Rn <= (int64_t)L.cnt && (zp >= Bn || zp <= -Bn)) {
                     L.ra0 = (uint32_t)na; L.rb0 = (uint32_t)nb; L.ok = 1u | 2u | ((uint32_t)r << 2);
                 } else if (L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
             }
@@ -299,25 +318,42 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
     return L;
 }
 
-// Expand leader values (already broadcast to this lane) into this lane's own term.
-// Returns false when the lane does not act in this trip.
+// A leader whose jump is shorter than the run (|jump| < B, on a path long enough to be expanded) is executed in TWO
+// trips, one per COLOUR: the run's terms (a+l, a+l+z), l = 0..B-1, chain through shared nodes (a_{l+z} = b_l), so
+// colour 0 holds the lanes with floor(l/|z|) even and colour 1 those with it odd — each colour is node-disjoint, and
+// together the two trips apply every term of the run exactly once, like a long-jump run does in one trip.  (Round 1
+// executed colour 0 only: short jumps then got half the updates the reference gives them, and the layout lost
+// precision exactly at step distances below B — profiles/r02/quality_probe_before.log.)
+template <int B>
+__device__ __forceinline__ bool two_colour(uint32_t ok, uint32_t cnt, uint32_t ra0, uint32_t rb0) {
+    if ((ok & 3u) != 1u || cnt < 2u * B) return false;
+    const int64_t s = (int64_t)rb0 - (int64_t)ra0;
+    return s < (int64_t)B && s > -(int64_t)B;                                          // s != 0 since ok & 1
+}
+
+// Expand leader values (already broadcast to this lane) into this lane's own term for trip `seg` of the run (0 .. K-1,
+// run_trips) and colour `colour` (0 for every leader; 1 only for two_colour leaders).  Returns false when the lane
+// does not act in this trip.
 template <int B>
 __device__ __forceinline__ bool expand_run(uint32_t ok, uint64_t first, uint32_t cnt, uint32_t ra0, uint32_t rb0,
-                                           int sub, uint64_t &sa, uint64_t &sb) {
+                                           int sub, uint32_t colour, uint32_t seg, uint64_t &sa, uint64_t &sb) {
     if (!(ok & 1u)) return false;
     if (ok & 2u) {                                                                     // both runs line-aligned blocks inside the path
-        sa = first + ra0 + (uint32_t)sub;
-        sb = first + rb0 + (((uint32_t)sub + ((ok >> 2) & 7u)) & (uint32_t)(B - 1));
+        if (colour) return false;
+        sa = first + ra0 + seg * (uint32_t)B + (uint32_t)sub;
+        sb = first + rb0 + seg * (uint32_t)B + (((uint32_t)sub + ((ok >> 2) & 7u)) & (uint32_t)(B - 1));
         return true;
     }
     uint32_t ra_l = ra0, rb_l = rb0;
-    if (sub != 0) {
+    const uint32_t l = seg * (uint32_t)B + (uint32_t)sub;                              // place in the run
+    if (l != 0 || colour) {
         if (cnt < 2u * B) return false;                                                // short path: leader only
         const int64_t shift = (int64_t)rb0 - (int64_t)ra0;
         const uint32_t z = (uint32_t)(shift < 0 ? -shift : shift);
-        if (z < (uint32_t)B && ((((uint32_t)sub) / z) & 1u)) return false;             // node-disjoint lanes only
-        ra_l = ra0 + (uint32_t)sub;
-        if (ra_l >= cnt) ra_l -= cnt;                                                  // wrap to the path start
+        if (z < (uint32_t)B) { if (((l / z) & 1u) != colour) return false; }           // node-disjoint lanes of this colour
+        else if (colour) return false;
+        ra_l = ra0 + l;
+        if (ra_l >= cnt) ra_l -= cnt;                                                  // wrap to the path start (run <= cnt/2 steps)
         int64_t t = (int64_t)ra_l + shift;
         if (t < 0 || t > (int64_t)cnt - 1) {
             // partner outside the path.  A step this close to a path end samples into the path in

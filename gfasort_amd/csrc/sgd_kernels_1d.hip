@@ -83,15 +83,44 @@ __global__ void sgd1d_kernel(const KArgs a) {
 // Per-wave state that survives from one iteration to the next inside a launch.
 struct TeamState {
     Rng rng;
-    // the wave's current pass: 64 leaders (one per lane) of which `left` trips have not been expanded yet.
+    // the wave's current pass: 64 leaders (one per lane) of which `left` trip slots have not been fully expanded yet
+    // (`colour` = 1: the current slot's first colour is done, its second is next — sgd_device.h two_colour).
     // A pass outlives the iteration it was sampled in (eta is not part of sampling); it is dropped when
     // the cooling phase — the only thing the sampler depends on besides the RNG — changes.
     Leader L = {0, 0, 0, 0, 0, 0};
-    uint32_t left = 0, cool = 0;
+    uint32_t left = 0, cool = 0, colour = 0, seg = 0;   // seg: next trip of the current slot's run (sgd_device.h run_trips)
     uint32_t done = 0, att = 0, ntr = 0;
     // deferred atomics of the previous trip: up to two adds per lane (normally -r to node i and +r to node j)
     bool p1f = false, p2f = false; uint32_t p1s = 0, p2s = 0; double p1v = 0.0, p2v = 0.0;
 };
+
+// One trip = (slot t of the pass, trip seg of its run, colour): what every lane needs to execute it.
+struct Trip {
+    uint64_t sa = 0, sb = 0;
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+    bool valid = false;
+    int mshift = 0;            // != 0: merged short-jump trip (sgd_kernel_common.h merged_trip_shift)
+    bool two = false;          // wave-uniform: some run of this slot has a second colour
+    bool near = false;         // wave-uniform: the run's next trip reads nodes this trip updates (|jump| < 2B)
+    uint32_t k = 1;            // wave-uniform: trips of this slot's run (long runs: B = 64 only)
+};
+
+template <int B>
+__device__ __forceinline__ void expand_trip(const KArgs &a, const Leader &L, int t, uint32_t seg, uint32_t colour, int sub, int q, Trip &tr) {
+    constexpr int RUNS = 64 / B;
+    const int ll = t * RUNS + q;
+    const uint32_t ok = bcast<B>(L.ok, ll), cnt = bcast<B>(L.cnt, ll), ra0 = bcast<B>(L.ra0, ll), rb0 = bcast<B>(L.rb0, ll);
+    tr.valid = expand_run<B>(ok, bcast_first<B>(L, ll), cnt, ra0, rb0, sub, colour, seg, tr.sa, tr.sb);
+    tr.mshift = merged_trip_shift<B>(ok, cnt, ra0, rb0, seg);
+    const bool two = !(a.dbg & 0x08u) && two_colour<B>(ok, cnt, ra0, rb0);
+    tr.two = B == 64 ? two : (__any(two) != 0);                       // B = 64: the leader is wave-uniform already
+    // long runs only where the whole wave follows one leader; a leader the reference rejected takes one (empty) trip
+    tr.k = (B == 64 && (ok & 1u) && cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, cnt) : 1u;
+    const int64_t s = (int64_t)rb0 - (int64_t)ra0;
+    tr.near = B == 64 && s < 2 * B && s > -2 * B;
+    tr.ra = make_uint4(0, 0, 0, 0); tr.rb = make_uint4(0, 0, 0, 0);
+    if (tr.valid) { tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb]; }
+}
 
 // One SGD iteration of one wave: passes and trips until the wave's quota is filled.
 template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
@@ -100,7 +129,6 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
     const int lane = threadIdx.x & 63;
     const int sub = lane & (B - 1);
     const int q = lane / B;
-    constexpr int RUNS = 64 / B;                                      // runs per trip
     const uint64_t max_passes = (uint64_t)a.attempt_factor * (wave_quota / (64u * B) + 1u) + 16u;
     uint64_t wave_done = 0, passes = 0;
     double *x = a.x;
@@ -108,36 +136,30 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
         if (ts.left == 0 || ts.cool != (uint32_t)a.it.cooling) {
             ++passes;
             ts.L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, ts.rng);
-            ts.left = B; ts.cool = (uint32_t)a.it.cooling;
+            ts.left = B; ts.cool = (uint32_t)a.it.cooling; ts.colour = 0; ts.seg = 0;
         }
         const Leader &L = ts.L;
-        const int t0 = B - (int)ts.left;
-        // trip t0: expand and request records
-        uint64_t sa = 0, sb = 0;
-        bool valid;
-        int mshift = 0;                                                // != 0: this trip is a merged short-jump trip
-        {
-            const int ll = t0 * RUNS + q;
-            valid = expand_run<B>(bcast<B>(L.ok, ll), bcast_first<B>(L, ll), bcast<B>(L.cnt, ll),
-                                  bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa, sb);
-            mshift = merged_trip_shift<B>(bcast<B>(L.ok, ll), bcast<B>(L.cnt, ll), bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll));
-        }
-        uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-        if (valid) { ra = a.step_rec[sa]; rb = a.step_rec[sb]; }
-        for (int t = t0; t < B; ++t) {
-            // request the records of trip t+1
-            uint64_t sa_n = 0, sb_n = 0; bool valid_n = false; int mshift_n = 0;
-            uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = make_uint4(0, 0, 0, 0);
-            if (t + 1 < B) {
-                const int ll = (t + 1) * RUNS + q;
-                valid_n = expand_run<B>(bcast<B>(L.ok, ll), bcast_first<B>(L, ll), bcast<B>(L.cnt, ll),
-                                        bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa_n, sb_n);
-                mshift_n = merged_trip_shift<B>(bcast<B>(L.ok, ll), bcast<B>(L.cnt, ll), bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll));
-                if (valid_n) { ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n]; }
-            }
-            // consume trip t
+        int t = B - (int)ts.left;
+        uint32_t colour = ts.colour, seg = ts.seg;
+        Trip cur;
+        expand_trip<B>(a, L, t, seg, colour, sub, q, cur);             // expand and request the records of the first trip
+        for (;;) {
+            // the trip after this one: this trip's second colour, else the run's next trip, else the next slot;
+            // request its records now
+            int t_n = t; uint32_t colour_n = 0u, seg_n = seg;
+            if (colour == 0 && cur.two) colour_n = 1u;
+            else if (seg + 1u < cur.k) seg_n = seg + 1u;
+            else { t_n = t + 1; seg_n = 0u; }
+            const bool have_n = t_n < B;
+            Trip nxt;
+            if (have_n) expand_trip<B>(a, L, t_n, seg_n, colour_n, sub, q, nxt);
+            // consume the current trip
             ++ts.att;
-            --ts.left;
+            ts.colour = colour_n; ts.seg = seg_n;
+            if (t_n != t) --ts.left;
+            bool valid = cur.valid;
+            const uint4 ra = cur.ra, rb = cur.rb;
+            const int mshift = cur.mshift;
             double term_dist = 0.0;
             uint32_t i = 0, j = 0;
             if (valid) {
@@ -153,12 +175,20 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
                 valid = rank < remaining;
             }
             wave_done += nvalid < remaining ? nvalid : remaining;
+            // A second-colour trip reads the nodes its first colour has just moved, and so does the next trip of a run
+            // whose jump is shorter than two trips: those adds go out first.
+            if (DEFER && (colour != 0 || (seg != 0 && cur.near)) && !(a.dbg & 1u)) {
+                if (ts.p1f) add_pos(x + ts.p1s, ts.p1v);
+                if (ts.p2f) add_pos(x + ts.p2s, ts.p2v);
+                ts.p1f = false; ts.p2f = false;
+            }
+            if ((a.dbg & 0x100u) && (colour != 0 || (seg != 0 && cur.near))) __builtin_amdgcn_s_waitcnt(0);   // experiment
             double xi = 0.0, xj = 0.0;
             if (valid) {
                 if (a.dbg & 2u) { xi = (double)i; xj = (double)j; }                    // ablation: no position loads
                 else { xi = load_pos<ATOMIC_LOADS>(x + i); xj = load_pos<ATOMIC_LOADS>(x + j); }   // :541-542
             }
-            if (DEFER) {                                                               // trip t-1's :575-576
+            if (DEFER) {                                                               // the previous trip's :575-576
                 if (a.dbg & 1u) { asm volatile("" :: "v"(ts.p1v), "v"(ts.p1s), "v"(ts.p2v), "v"(ts.p2s)); }   // ablation: no atomics
                 else {
                     if (ts.p1f) add_pos(x + ts.p1s, ts.p1v);
@@ -195,7 +225,7 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
                 const double rv = __shfl(r_x, srcc, 64);
                 const uint32_t js = (uint32_t)__shfl((int)j, srcc, 64);
                 const int vs = __shfl((int)valid, srcc, 64);
-                const bool resting = (((uint32_t)lane / (uint32_t)z) & 1u) != 0u;
+                const bool resting = (((seg * 64u + (uint32_t)lane) / (uint32_t)z) & 1u) != colour;
                 if (resting && src >= 0 && src < 64 && vs) { o1f = true; o1s = js; o1v = rv; }
                 const int dst = lane + mshift;                                         // where my own partner sits
                 o2f = valid && (dst < 0 || dst > 63);                                  // beyond the run: add it myself
@@ -205,8 +235,9 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
                 if (o1f) add_pos(x + o1s, o1v);
                 if (o2f) add_pos(x + o2s, o2v);
             }
-            if (wave_done >= wave_quota) break;                                        // leaders left over serve the next iteration
-            ra = ra_n; rb = rb_n; sa = sa_n; sb = sb_n; valid = valid_n; mshift = mshift_n;
+            if (wave_done >= wave_quota) break;                                        // what is left of the pass serves the next iteration
+            if (!have_n) break;
+            cur = nxt; t = t_n; colour = colour_n; seg = seg_n;
         }
     }
 }
@@ -222,14 +253,14 @@ __device__ __forceinline__ void load_pass(const KArgs &a, uint32_t tid, TeamStat
     ts.L.first_lo = a.lead[tid]; ts.L.first_hi = a.lead[T + tid]; ts.L.cnt = a.lead[2 * T + tid];
     ts.L.ra0 = a.lead[3 * T + tid]; ts.L.rb0 = a.lead[4 * T + tid];
     const uint32_t w = a.lead[5 * T + tid];
-    ts.L.ok = w & 0xFFu; ts.left = (w >> 8) & 0xFFu; ts.cool = (w >> 16) & 1u;
+    ts.L.ok = w & 0xFFu; ts.left = (w >> 8) & 0xFFu; ts.cool = (w >> 16) & 1u; ts.colour = (w >> 17) & 1u; ts.seg = (w >> 18) & 0xFFu;
 }
 __device__ __forceinline__ void store_pass(const KArgs &a, uint32_t tid, const TeamState &ts) {
     if (!a.lead) return;
     const uint64_t T = a.n_streams;
     a.lead[tid] = ts.L.first_lo; a.lead[T + tid] = ts.L.first_hi; a.lead[2 * T + tid] = ts.L.cnt;
     a.lead[3 * T + tid] = ts.L.ra0; a.lead[4 * T + tid] = ts.L.rb0;
-    a.lead[5 * T + tid] = (ts.L.ok & 0xFFu) | (ts.left << 8) | (ts.cool << 16);
+    a.lead[5 * T + tid] = (ts.L.ok & 0xFFu) | (ts.left << 8) | (ts.cool << 16) | (ts.colour << 17) | (ts.seg << 18);
 }
 
 __device__ __forceinline__ uint64_t wave_quota_of(const KArgs &a, uint32_t tid) {

@@ -48,8 +48,8 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
         uint64_t sa = 0, sb = 0;
         uint64_t first = bcast_first<B>(L, q); uint32_t cnt = bcast<B>(L.cnt, q);
         uint32_t flips = bcast<B>(lflips, q);
-        bool valid = expand_run<B>(bcast<B>(L.ok, q), first, cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, sa, sb);
-        int mshift = merged_trip_shift<B>(bcast<B>(L.ok, q), cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q));   // see sgd_kernel_common.h
+        bool valid = expand_run<B>(bcast<B>(L.ok, q), first, cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, 0u, 0u, sa, sb);
+        int mshift = merged_trip_shift<B>(bcast<B>(L.ok, q), cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), 0u);   // see sgd_kernel_common.h
         uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, na = ra, nb = ra;
         if (valid) {
             ra = a.step_rec[sa]; rb = a.step_rec[sb];
@@ -62,8 +62,8 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
             if (t + 1 < B) {
                 const int ll = (t + 1) * RUNS + q;
                 first_n = bcast_first<B>(L, ll); cnt_n = bcast<B>(L.cnt, ll); flips_n = bcast<B>(lflips, ll);
-                valid_n = expand_run<B>(bcast<B>(L.ok, ll), first_n, cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, sa_n, sb_n);
-                mshift_n = merged_trip_shift<B>(bcast<B>(L.ok, ll), cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll));
+                valid_n = expand_run<B>(bcast<B>(L.ok, ll), first_n, cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, 0u, 0u, sa_n, sb_n);
+                mshift_n = merged_trip_shift<B>(bcast<B>(L.ok, ll), cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), 0u);
                 if (valid_n) {
                     ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n];
                     na_n = a.step_rec[sa_n + 1u < a.n_steps ? sa_n + 1u : sa_n];

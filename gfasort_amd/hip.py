@@ -14,6 +14,15 @@ OK, NOTHING_TO_DO = 0, 1
 F_PLAIN_LOADS, F_NO_LDS_TABLES, F_NO_FUSE = 1, 2, 4
 
 
+F_DBG_NO_ATOMICS, F_DBG_NO_XLOADS, F_DBG_NO_DEFER, F_DBG_ONE_COLOUR = 0x100, 0x200, 0x400, 0x800
+F_DBG_NO_ALIGN, F_DBG_ALIGN_FIRST, F_DBG_WIDE_INDEX = 0x1000, 0x2000, 0x4000
+
+
+def F_CHAIN(k):
+    """GFS_F_CHAIN(k): longest run in trips at B = 64 (0 = auto = 16, else a power of two <= 64)."""
+    return (int(k) & 0xFF) << 24
+
+
 def F_BUNDLE(n):
     """GFS_F_BUNDLE(n): 0 = auto, 1 = reference streams, 4..64 = explicit bundle width."""
     return (int(n) & 0xFF) << 16
@@ -53,7 +62,7 @@ class LaunchConfig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("term_updates", C.c_uint64), ("attempts", C.c_uint64), ("iterations", C.c_uint64),
                 ("n_streams", C.c_uint64), ("bundle", C.c_uint64), ("kernel_ms", C.c_double),
-                ("total_ms", C.c_double), ("launches", C.c_uint64)]
+                ("total_ms", C.c_double), ("launches", C.c_uint64), ("run_trips", C.c_uint64)]
 
 
 TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)

@@ -104,12 +104,17 @@ typedef struct gfs_launch_config {
  * reference worker thread.  n = 0 (default): the library picks by graph size — 1 for small
  * graphs (< 16384 nodes), else up to 64 while an iteration still has >= 4096 independent draws. */
 #define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* n in {0 = auto, 1, 4, 8, 16, 32, 64} */
+/* Long runs: with bundles of 64 a sampled (step a, jump) is expanded over k consecutive trips of its wave, i.e. over
+ * 64*k consecutive steps (k adapts downwards on short paths).  k = 0 (default): 16.  k = 1: a run is one trip. */
+#define GFS_F_CHAIN(k) (((uint32_t)(k) & 0xFFu) << 24)   /* k in {0 = auto, 1, 2, 4, 8, 16, 32, 64} */
 #define GFS_F_NO_FUSE       4u        /* gfs_ctx_run / gfs_ctx_run_range: one launch per iteration even where
                                          a fused persistent launch is possible                        */
 #define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
 #define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
 #define GFS_F_DBG_NO_DEFER    0x400u  /* test hook: team kernels issue a trip's adds in that trip (one wave is then
                                          an exact replay of the oracle's sequential mirror)                   */
+#define GFS_F_DBG_ONE_COLOUR   0x800u  /* diagnostic: short-jump runs execute their first colour only (round-1 behaviour:
+                                         half of the run's terms, i.e. short jumps under-sampled)                  */
 #define GFS_F_DBG_NO_ALIGN      0x1000u /* diagnostic: bundled sampler without line-aligned runs               */
 #define GFS_F_DBG_ALIGN_FIRST   0x2000u /* diagnostic: line-align only the first run of a bundle               */
 #define GFS_F_DBG_WIDE_INDEX 0x4000u  /* test hook: draw step indices with the u64 sampler that graphs of
@@ -124,6 +129,7 @@ typedef struct gfs_stats {
     double   kernel_ms;               /* sum of SGD kernel durations (HIP events)            */
     double   total_ms;                /* wall time inside the call (one-shot) / run          */
     uint64_t launches;                /* SGD kernel launches (a fused launch covers many iterations) */
+    uint64_t run_trips;               /* longest run in trips (GFS_F_CHAIN) actually used; 1 = one trip per run */
 } gfs_stats;
 
 /* One sampled term (debug trace): 1D i,j = dense node index; nD = 2*idx+end. */

@@ -526,7 +526,9 @@ struct gfo_state {
     zipf_env z;
     uint64_t T, D, quota_total, attempt_factor, bundle;
     uint64_t *rng, *done, *att, *ntr;
-    struct leader_s *lead; uint8_t *lead_left, *lead_cool;   /* 1D bundled mode: each wave's partly expanded pass */
+    struct leader_s *lead; uint8_t *lead_left, *lead_cool, *lead_colour, *lead_seg;   /* 1D bundled mode: each wave's partly expanded pass */
+    uint64_t chain;                                           /* longest run in trips (B = 64, 1D); mirror of GFS_F_CHAIN */
+    int one_colour;                                           /* mirror of GFS_F_DBG_ONE_COLOUR */
     uint32_t *node_slot;                                     /* bundled mode: the product's internal node layout (line-aligned runs) */
     gfo_term *trace; uint64_t trace_per_stream;
     uint64_t total_upd, total_att, iterations;
@@ -537,7 +539,7 @@ void gfo_state_destroy(gfo_state *s) {
     if (!s) return;
     pidx_free(&s->pi);
     free(s->etas); free(s->zetas); free(s->rng); free(s->done); free(s->att); free(s->ntr);
-    free(s->lead); free(s->lead_left); free(s->lead_cool); free(s->node_slot);
+    free(s->lead); free(s->lead_left); free(s->lead_cool); free(s->lead_colour); free(s->lead_seg); free(s->node_slot);
     free(s);
 }
 
@@ -550,7 +552,7 @@ int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas
     gfo_state *s = (gfo_state *)calloc(1, sizeof *s);
     if (!s) return -2;
     if (pidx_build(g, 1, &s->pi)) { gfo_state_destroy(s); return -2; }
-    s->p = *p; s->T = n_streams; s->D = dims; s->bundle = 1;
+    s->p = *p; s->T = n_streams; s->D = dims; s->bundle = 1; s->chain = 1;
     s->quota_total = quota_total ? quota_total : p->min_term_updates;
     s->attempt_factor = attempt_factor ? attempt_factor : 64;
     s->etas = (double *)malloc((p->iter_max + 1) * 8);
@@ -597,6 +599,28 @@ int gfo_state_set_bundle(gfo_state *s, uint64_t bundle) {
     if (bundle != 1 && (s->T % 64 != 0 || (bundle != 4 && bundle != 8 && bundle != 16 && bundle != 32 && bundle != 64)))
         return -1;
     s->bundle = bundle;
+    return 0;
+}
+
+/* Long runs (product: sgd_device.h run_trips): with B = 64 in 1D a leader is expanded over K consecutive trips of its
+ * wave, K = the largest power of two <= chain with K*B <= cnt/4.  chain = 1: a run is one trip. */
+int gfo_state_set_chain(gfo_state *s, uint64_t chain) {
+    if (!s || chain == 0 || chain > 64 || (chain & (chain - 1))) return -1;
+    s->chain = chain;
+    return 0;
+}
+static uint64_t run_trips(const gfo_state *s, uint64_t cnt) {
+    if (s->bundle != 64 || s->D != 0) return 1;
+    const uint64_t room = cnt / (4 * s->bundle);
+    if (room < 2 || s->chain < 2) return 1;
+    uint64_t p2 = 1; while (p2 * 2 <= room) p2 *= 2;
+    return p2 < s->chain ? p2 : s->chain;
+}
+
+/* mirror of GFS_F_DBG_ONE_COLOUR: short-jump runs execute their first colour only (the round-1 sampler) */
+int gfo_state_set_one_colour(gfo_state *s, int on) {
+    if (!s) return -1;
+    s->one_colour = on ? 1 : 0;
     return 0;
 }
 
@@ -673,13 +697,14 @@ static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t
     uint32_t node0 = pi->rec[s0].node;
     if (L.ok && L.cnt >= 2 * s->bundle && node0 != GFO_NO_NODE) {        /* only where a run will be expanded */
         const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0, Bn = (int64_t)s->bundle;
+        const int64_t Rn = Bn * (int64_t)run_trips(s, L.cnt);              /* steps of the whole run */
         if (jump >= Bn + 8 || jump <= -(Bn + 8)) {                     /* shorter jumps are left alone */
             const int64_t A = Bn < 8 ? Bn : 8;                            /* runs shorter than a line: align to the run length */
             const uint64_t sh = (s->node_slot ? s->node_slot[node0] : node0) & (uint64_t)(A - 1);
             if (L.ra0 >= sh) {
                 const int64_t na = (int64_t)L.ra0 - (int64_t)sh;
                 const int64_t r = ((jump % A) + A) % A, zp = jump - r, nb = na + zp;
-                if (na + Bn <= (int64_t)L.cnt && nb >= 0 && nb + Bn <= (int64_t)L.cnt && (zp >= Bn || zp <= -Bn)) {
+                if (na + Rn <= (int64_t)L.cnt && nb >= 0 && nb + Rn <= (int64_t)L.cnt && (zp >= Bn || zp <= -Bn)) {
                     L.ra0 = (uint64_t)na; L.rb0 = (uint64_t)nb; L.aligned = 1; L.rot = (int)r;
                 } else if (L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
             }
@@ -708,6 +733,7 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
         if (!s->lead) {
             s->lead = (leader_t *)calloc(T, sizeof(leader_t));
             s->lead_left = (uint8_t *)calloc(T / 64, 1); s->lead_cool = (uint8_t *)calloc(T / 64, 1);
+            s->lead_colour = (uint8_t *)calloc(T / 64, 1); s->lead_seg = (uint8_t *)calloc(T / 64, 1);
         }
         leader_t *L = s->lead + wave_first;
         int lead_fa[64] = {0}, lead_fb[64] = {0};
@@ -721,10 +747,26 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                         lead_fb[l] = (int)flip(s->rng + 4 * (wave_first + l));
                     }
                 }
-                s->lead_left[w] = (uint8_t)B; s->lead_cool[w] = (uint8_t)it.cooling;
+                s->lead_left[w] = (uint8_t)B; s->lead_cool[w] = (uint8_t)it.cooling; s->lead_colour[w] = 0; s->lead_seg[w] = 0;
             }
-            for (uint64_t t = B - s->lead_left[w]; t < B && wave_done < wave_quota; t++) {
-                s->lead_left[w]--;
+            /* trips: slot t of the pass, colour 0, then — when some run of the slot has a jump shorter than the run
+             * (1D only; sgd_device.h two_colour) — the same slot with colour 1: the run's terms chain through shared
+             * nodes, each colour is node-disjoint, together they are every term of the run */
+            while (s->lead_left[w] > 0 && wave_done < wave_quota) {
+                const uint64_t t = B - s->lead_left[w];
+                const uint64_t colour = s->lead_colour[w], seg = s->lead_seg[w];
+                int two = 0;
+                for (uint64_t qq = 0; qq < RUNS && carry && !s->one_colour; qq++) {
+                    const leader_t *ld = &L[t * RUNS + qq];
+                    const int64_t shift = (int64_t)ld->rb0 - (int64_t)ld->ra0;
+                    if (ld->ok && !ld->aligned && ld->cnt >= 2 * B && shift < (int64_t)B && shift > -(int64_t)B) two = 1;
+                }
+                /* trips of this slot's run (B = 64: one leader per trip) */
+                const uint64_t ktrips = (RUNS == 1 && L[t].ok && L[t].cnt >= 2 * B) ? run_trips(s, L[t].cnt) : 1;
+                /* what comes next: this trip's second colour, else the run's next trip, else the next slot */
+                if (colour == 0 && two) s->lead_colour[w] = 1;
+                else if (seg + 1 < ktrips) { s->lead_colour[w] = 0; s->lead_seg[w] = (uint8_t)(seg + 1); }
+                else { s->lead_colour[w] = 0; s->lead_seg[w] = 0; s->lead_left[w]--; }
                 int valid[64], flips_a[64], flips_b[64]; uint64_t sa[64], sb[64];
                 uint64_t nvalid = 0;
                 for (uint64_t qq = 0; qq < RUNS; qq++) {
@@ -733,15 +775,18 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                     const uint64_t zabs = (uint64_t)(shift < 0 ? -shift : shift);
                     for (uint64_t sub = 0; sub < B; sub++) {
                         const uint64_t l = qq * B + sub;
+                        const uint64_t pl = seg * B + sub;              /* place in the run */
                         valid[l] = 0;
                         if (!ld->ok) continue;
                         uint64_t ra = ld->ra0, rb = ld->rb0;
                         if (ld->aligned) {                              /* both runs are aligned blocks inside the path */
-                            ra = ld->ra0 + sub; rb = ld->rb0 + ((sub + (uint64_t)ld->rot) % B);
-                        } else if (sub != 0) {
+                            if (colour) continue;
+                            ra = ld->ra0 + pl; rb = ld->rb0 + seg * B + ((sub + (uint64_t)ld->rot) % B);
+                        } else if (pl != 0 || colour) {
                             if (ld->cnt < 2 * B) continue;
-                            if (zabs < B && ((sub / zabs) & 1)) continue;
-                            ra = ld->ra0 + sub;
+                            if (zabs < B) { if (((pl / zabs) & 1) != colour) continue; }
+                            else if (colour) continue;
+                            ra = ld->ra0 + pl;
                             if (ra >= ld->cnt) ra -= ld->cnt;
                             int64_t tt = (int64_t)ra + shift;
                             if (tt < 0 || tt > (int64_t)ld->cnt - 1) {          /* mirror the jump (|jump| >= B only) */

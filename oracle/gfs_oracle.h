@@ -122,6 +122,8 @@ int  gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *eta
 /* bundle > 1: mirror of the product's bundled ("run") sampler — NOT a reference mode; 1D only,
  * n_streams % 64 == 0, bundle in {4,8,16,32,64}.  See gfs_oracle.c. */
 int  gfo_state_set_bundle(gfo_state *s, uint64_t bundle);
+int  gfo_state_set_chain(gfo_state *s, uint64_t chain);  /* mirror of GFS_F_CHAIN: longest run in trips (B = 64, 1D) */
+int  gfo_state_set_one_colour(gfo_state *s, int on);   /* mirror of GFS_F_DBG_ONE_COLOUR */
 /* bundled mode: the product's internal node layout (slot of dense node k), to mirror its line-aligned runs; NULL = identity */
 int  gfo_state_set_node_slots(gfo_state *s, const uint32_t *slot);
 int  gfo_state_run_iteration(gfo_state *s, uint64_t k, double *x);

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(hip.LayoutParams) == 15 * 8
     assert C.sizeof(hip.GraphView) == 7 * 8
     assert C.sizeof(hip.LaunchConfig) == 4 * 8 + 8 + 8
-    assert C.sizeof(hip.Stats) == 8 * 8
+    assert C.sizeof(hip.Stats) == 9 * 8
     assert hip.TERM_DTYPE.itemsize == 16
 
 

@@ -264,6 +264,11 @@ def _node_slots(g):
     return path_order_layout(g)
 
 
+def _mirror_chain(B):
+    """The product's default run length in trips (GFS_F_CHAIN auto): 16 at B = 64 in 1D, else one trip per run."""
+    return 16 if B == 64 else 1
+
+
 
 @pytest.mark.parametrize("B", [4, 8, 16, 32, 64])
 def test_bundled_sampler_trace_matches_oracle_mirror(B):
@@ -273,7 +278,7 @@ def test_bundled_sampler_trace_matches_oracle_mirror(B):
     p = _ygs(g, 6)
     T, K = 512, 48
     og, op = oracle_graph(g), oracle_params(p)
-    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g))
+    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g), chain=_mirror_chain(B))
     x_ref = O.init_positions(og)
     st_o.run(x_ref)
     so = st_o.stats()
@@ -615,7 +620,7 @@ def test_wide_index_path_matches_oracle(bundle):
     og, op = oracle_graph(g), oracle_params(p)
     O.lib().gfo_set_force_wide_steps(1)
     try:
-        st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=bundle, node_slots=_node_slots(g))
+        st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=bundle, node_slots=_node_slots(g), chain=_mirror_chain(bundle))
         x_ref = O.init_positions(og)
         st_o.run(x_ref)
         so = st_o.stats()
@@ -878,7 +883,7 @@ def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(fused):
     p.iter_max = 8
     p.min_term_updates = 200_000
     og, op = oracle_graph(g), oracle_params(p)
-    st_o = O.State(og, op, n_streams=64, bundle=64, node_slots=_node_slots(g))
+    st_o = O.State(og, op, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64))
     x_ref = O.init_positions(og)
     st_o.run(x_ref)
     so = st_o.stats()
