@@ -14,7 +14,7 @@ LIB     := $(LIBDIR)/libgfasort_hip.so
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function
 CXXFLAGS := -O2 -std=c++17 -Wall -ffp-contract=off
 
-KERNELS := sgd_kernels_1d sgd_kernels_nd sgd_kernels_nd_team index_kernels capi
+KERNELS := sgd_kernels_1d sgd_kernels_nd sgd_kernels_nd_team index_kernels capi multi
 OBJS    := $(KERNELS:%=$(OBJDIR)/%.o)
 HDRS    := $(CSRC)/sgd_device.h $(CSRC)/sgd_kernel_common.h include/gfasort_hip.h
 HOSTSRC := $(HOST)/graph.cpp $(HOST)/sgd.cpp

@@ -12,8 +12,10 @@ streams are resident in HBM before the timed region starts.
     python bench.py --gpus 1 --steps 201 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N>1: paths are sharded over ranks, positions replicated, one RCCL all-reduce of the position
-deltas per iteration (gfasort_amd/distributed.py) — total work is fixed => "strong" scaling.
+N>1: BASELINE configs[4] — windows(N=1e7, P=1024, W=97656, seed=3), 1e8 steps, -p Y --iter-max 100 — with the paths
+sharded over the ranks (gfs_rank below the C ABI, gfasort_amd/distributed.py RankDriver) and ONE RCCL all-reduce per
+merge window of the slots two or more ranks can move.  The graph is fixed, the ranks split each iteration's 1e8 term
+updates => "strong" scaling; rank 0 also times the same workload on its GPU alone (`single_gpu_same_workload`).
 """
 import argparse
 import json
@@ -30,12 +32,20 @@ ALGO_BYTES_1D = 64          # 2 step records x16 B + 2 positio
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def build_workload():
+def build_workload(world=1):
+    """N = 1: BASELINE configs[2] (the configuration the metric is quoted on).  N > 1: configs[4]."""
     from gfasort_amd import graph as G, params as P
+    if world > 1:
+        g = G.synth_windows(10_000_000, 1024, 97_656, 3)
+        p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+        p.iter_max = 100
+        return g, p, ("windows(N=10000000,P=1024,W=97656,seed=3): 10M nodes / 1024 paths / 1e8 steps, -p Y --iter-max 100, "
+                      "1e8 term updates per step")
     g = G.synth_windows(1_000_000, 64, 156_250, 2)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
     p.iter_max = 200
-    return g, p
+    return g, p, ("windows(N=1000000,P=64,W=156250,seed=2): 1M nodes / 64 paths / 10M steps, -p Y --iter-max 200, "
+                  "1e7 term updates per step")
 
 
 def host_cores():
@@ -70,10 +80,74 @@ def cpu_baseline(g, p, seconds=12.0):
     x2 = O.init_positions(og)
     rc2, st2 = O.sgd_1d_threads(og, op, x2, flat=1, max_seconds=seconds / 2, etas=etas, zts=zts)
     val_flat = st2.term_updates / st2.seconds if st2.seconds > 0 else 0.0
+    # one worker thread ("1 thread, and all host cores"), same port, shorter sample
+    op1 = O.params(nthreads=1, **kw)
+    x3 = O.init_positions(og)
+    rc3, st3 = O.sgd_1d_threads(og, op1, x3, flat=0, max_seconds=seconds / 2, etas=etas, zts=zts)
+    val_1t = st3.term_updates / st3.seconds if st3.seconds > 0 else 0.0
     return {"value": val, "unit": "term-updates/s", "cores": cores, "kind": "port",
             "sample": f"same 1M-node/10M-step graph, reference-like Hogwild port for {st.seconds:.1f} s "
                       f"({st.term_updates} updates, {st.iterations} iterations reached)",
-            "flat_variant_value": val_flat}
+            "flat_variant_value": val_flat,
+            "one_thread": {"value": val_1t, "cores": 1,
+                           "sample": f"same port, 1 worker thread for {st3.seconds:.1f} s ({st3.term_updates} updates)"}}
+
+
+def quality_leg(g, p, device_index, args):
+    """The whole `-p Y --iter-max 200` run of the timed configuration, from the reference's start, with the flags of the
+    timed region: exact update count, adjacent inversions of the sort against the chain the graph is (P1: 0 expected),
+    sampled stress before/after (the formula of sgd.rs:1196, gfasort_amd/quality.py), measure_layout_quality's RMSE."""
+    from gfasort_amd import hip, quality as Q
+    ctx = hip.Context(g, device=device_index)
+    ctx.setup_1d(p, hip.make_config(n_streams=args.streams, flags=args.flags | hip.F_BUNDLE(args.bundle), block_size=args.block))
+    ctx.init_positions()
+    x0 = ctx.download()
+    t0 = time.perf_counter()
+    ctx.run()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    x = ctx.download()
+    order = ctx.sort_order().astype(np.int64)
+    ctx.close()
+    lq = Q.layout_quality(g, order)
+    return {"iterations": int(st.iterations), "term_updates": int(st.term_updates),
+            "expected_term_updates": int((p.iter_max + 1) * p.min_term_updates), "launches": int(st.launches),
+            "seconds": dt, "inversions_vs_chain_order": Q.inversions_vs_chain(g.node_ids[order].astype(np.int64)),
+            "sampled_stress_before": Q.sampled_stress(g, x0, 0, 200000), "sampled_stress_after": Q.sampled_stress(g, x, 0, 200000),
+            "layout_quality_rmse_bp": lq["rmse"], "layout_quality_mae_bp": lq["mae"]}
+
+
+def bubbles_leg(device_index, args):
+    """A graph that is NOT a chain: synth_bubbles(400000, 24, 6) — 525k nodes, 24 haplotypes, SNP bubbles and insertions,
+    the default `-p Y` (iter_max 100).  Default flags against reference streams (GFS_F_BUNDLE(1)) at equal update counts:
+    rate, sampled stress (2M pairs), the worst ratio of the relative error over the octaves of path distance, Kendall tau."""
+    from gfasort_amd import graph as G, params as P, hip, quality as Q
+    g = G.synth_bubbles(400_000, 24, 6)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    ctx = hip.Context(g, device=device_index)
+    res = {}
+    for name, flags in (("default_flags", args.flags | hip.F_BUNDLE(args.bundle)), ("reference_streams", hip.F_BUNDLE(1))):
+        ctx.setup_1d(p, hip.make_config(n_streams=args.streams, flags=flags, block_size=args.block))
+        ctx.init_positions()
+        ctx.run()
+        st = ctx.stats()
+        x = ctx.download()
+        _, rms, _ = Q.stress_by_scale(g, x, 0, 1_000_000)
+        res[name] = {"value": st.term_updates / (st.kernel_ms * 1e-3), "unit": "term-updates/s", "sampling_bundle": int(st.bundle),
+                     "run_trips": int(st.run_trips), "n_streams": int(st.n_streams), "term_updates": int(st.term_updates),
+                     "sampled_stress_2M_pairs": Q.sampled_stress(g, x, 0, 2_000_000),
+                     "roofline_frac": st.term_updates * ALGO_BYTES_1D / (st.kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "_rms": rms, "_order": ctx.sort_order().astype(np.int64)}
+    ctx.close()
+    a, b = res["default_flags"], res["reference_streams"]
+    ra = Q.ranks_of(b.pop("_order"))
+    rb = Q.oriented(ra, Q.ranks_of(a.pop("_order")))
+    ratio = a.pop("_rms") / b.pop("_rms")
+    res["workload"] = "synth_bubbles(400000,24,6): 525000 nodes / 24 paths / 9.75e6 steps, -p Y --iter-max 100"
+    res["stress_ratio_default_over_reference_streams"] = a["sampled_stress_2M_pairs"] / b["sampled_stress_2M_pairs"]
+    res["worst_error_ratio_over_octaves_of_path_distance"] = float(ratio.max())
+    res["kendall_tau_of_the_two_sorts"] = Q.kendall_tau(ra, rb)
+    return res
 
 
 def reference_streams_leg(g, p, device_index, args, steps=60):
@@ -185,9 +259,11 @@ def main():
     ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--bundle", type=int, default=0, help="sampling bundle: 0 = library auto policy, 1 = reference streams")
-    ap.add_argument("--merge-every", type=int, default=8,
-                    help="N>1: iterations between replica merges (all-reduce); quality at 8 ranks measured in "
-                         "profiles/r01/virtual_cluster.log")
+    ap.add_argument("--merge-every", type=int, default=1,
+                    help="N>1: iterations per merge window (one all-reduce per window); 1 = an all-reduce at every "
+                         "iteration, as BASELINE's north_star has it")
+    ap.add_argument("--whole-vector", action="store_true", help="N>1: exchange the whole position vector, not only the shared slots")
+    ap.add_argument("--payload-f64", action="store_true", help="N>1: f64 exchange buffer instead of f32")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-fuse", action="store_true",
                     help="one kernel launch per iteration instead of one fused persistent launch per merge window")
@@ -196,7 +272,7 @@ def main():
     import torch
     import torch.distributed as dist
     from gfasort_amd import hip
-    from gfasort_amd.distributed import ShardedSGD, hip_engine_factory
+    from gfasort_amd.distributed import RankDriver
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -224,16 +300,14 @@ def main():
             dist.all_reduce(t)
             torch.cuda.synchronize()
 
-    g, p = build_workload()
+    g, p, workload = build_workload(world)
     M = int(p.min_term_updates)
     if args.no_fuse:
         args.flags |= hip.F_NO_FUSE
-    runner = ShardedSGD(g, p, rank, world,
-                        hip_engine_factory(device_index=local_rank, flags=args.flags | hip.F_BUNDLE(args.bundle),
-                                           block_size=args.block),
-                        dims=0, streams_per_rank=args.streams, dist=dist if world > 1 else None,
-                        merge_every=args.merge_every)
-    x0 = hip.init_positions(g)
+    runner = RankDriver(g, p, rank, world, dims=0, device_index=local_rank, streams_per_rank=args.streams,
+                        flags=args.flags | hip.F_BUNDLE(args.bundle), block_size=args.block,
+                        dist=dist if world > 1 else None, merge_every=args.merge_every, whole_vector=args.whole_vector,
+                        payload_f64=args.payload_f64)
     n_sched = int(p.iter_max) + 1
 
     def sync_all():
@@ -243,15 +317,15 @@ def main():
             torch.cuda.synchronize()
 
     # warmup (untimed), then restore the initial state so the timed run is a true run from k=0
-    runner.set_positions(x0)
+    runner.set_positions(None)                                      # the reference's start, computed on the device
     # (one launch per warm-up step: the fused kernel's only dispatch is then the timed one, so its rocprofv3
     # --stats average is directly the figure reported below)
     for s in range(args.warmup):
         runner.run_iteration(s % n_sched)
     sync_all()
-    runner.engine.reset_streams()
-    runner.set_positions(x0)
-    st0 = runner.engine.stats()
+    runner.reset_streams()
+    runner.set_positions(None)
+    st0 = runner.stats()
     sync_all()
 
     t0 = time.perf_counter()
@@ -259,9 +333,10 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
 
-    st1 = runner.engine.stats()
+    st1 = runner.stats()
     local_updates = st1.term_updates - st0.term_updates
     local_kernel_ms = st1.kernel_ms - st0.kernel_ms
+    multi = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -269,6 +344,36 @@ def main():
         u = torch.tensor([float(local_updates)], dtype=torch.float64, device="cuda")
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         total_updates = int(u.item())
+        # a short instrumented pass after the timed region: where a window's time goes (HIP events on rank 0's stream)
+        runner.profile = True
+        runner.run_range([s % n_sched for s in range(min(args.steps, 24))])
+        tm = runner.collect_timing()
+        runner.profile = False
+        sync_all()
+        info = runner.info
+        multi = {"merge_every": args.merge_every, "windows_profiled": tm["windows"],
+                 "compute_ms_per_window": tm["compute_ms"] / max(tm["windows"], 1),
+                 "exchange_ms_per_window": tm["exchange_ms"] / max(tm["windows"], 1),
+                 "exchange_bytes_per_window": tm["exchange_bytes_per_window"],
+                 "shared_slots": int(info.shared_slots), "n_nodes": g.n_nodes,
+                 "payload": "f64" if args.payload_f64 else "f32", "rank0_quota": int(info.quota),
+                 "note": "compute = this rank's kernels of the window + packing its moves; exchange = the all-reduce of "
+                         "[delta, touched] over the shared slots + applying it"}
+        # the same workload on ONE GPU (rank 0's), so that the scaling of THIS workload can be read off this line
+        if rank == 0:
+            ctx1 = hip.Context(g, device=local_rank)
+            ctx1.setup_1d(p, hip.make_config(n_streams=args.streams, flags=args.flags | hip.F_BUNDLE(args.bundle), block_size=args.block))
+            ctx1.init_positions()
+            ctx1.run_iteration(0)
+            ctx1.synchronize()
+            t1 = time.perf_counter()
+            ks1 = [s % n_sched for s in range(min(args.steps, 20))]
+            ctx1.run_range(ks1)
+            ctx1.synchronize()
+            dt1 = time.perf_counter() - t1
+            multi["single_gpu_same_workload"] = {"value": len(ks1) * M / dt1, "unit": "term-updates/s", "steps": len(ks1)}
+            ctx1.close()
+        sync_all()
     else:
         total_updates = int(local_updates)
 
@@ -278,13 +383,18 @@ def main():
         avg_kernel_s = (local_kernel_ms / launches) * 1e-3
         upd_per_launch = local_updates / launches
         achieved = upd_per_launch * ALGO_BYTES_1D / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-        traffic = None
+        # HBM traffic is a PMC measurement (separate rocprofv3 --pmc passes, MI355X_MICROARCH.md) and cannot be taken
+        # inside this run: the figure of the committed passes over this same command is scaled to this launch and LABELLED
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if world == 1 and os.path.exists(tpath):
             try:
                 with open(tpath) as fh:
-                    per_update = json.load(fh).get("hbm_bytes_per_update")
+                    tj = json.load(fh)
+                per_update = tj.get("hbm_bytes_per_update")
                 traffic = per_update * upd_per_launch if per_update else None
+                traffic_source = ("NOT measured in this run: " + str(tj.get("source", "profiles/traffic_latest.json")) +
+                                  f" ({per_update:.1f} B per update) scaled to this launch's updates")
             except Exception:
                 traffic = None
         out = {
@@ -293,15 +403,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "windows(N=1000000,P=64,W=156250,seed=2): 1M nodes / 64 paths / 10M steps, "
-                                   "-p Y --iter-max 200, 1e7 term updates per step",
+            "config": {"workload": workload,
                        "term_updates_per_step": M, "n_streams_per_gpu": int(st1.n_streams),
-                       "sampling_bundle": int(st1.bundle),
-                       "parallelism": f"paths sharded x{world}, positions replicated, f32 [delta,touched] all-reduce "
-                                      f"every {args.merge_every} iterations"
+                       "sampling_bundle": int(st1.bundle), "run_trips": int(st1.run_trips),
+                       "parallelism": f"paths sharded x{world} (consecutive blocks), one RCCL all-reduce of [delta,touched] "
+                                      f"over the slots two or more ranks can move, every {args.merge_every} iteration(s)"
                        if world > 1 else "single GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ("gfs::sgd1d_team_fused_kernel" if launches < args.steps else "gfs::sgd1d_team_kernel")
                                    if int(st1.bundle) != 1 else "gfs::sgd1d_kernel",
                          "launches": launches, "iterations_per_launch": args.steps / launches,
@@ -310,6 +419,11 @@ def main():
                          "algorithmic_bytes_per_update": ALGO_BYTES_1D},
             "total_term_updates": total_updates,
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
+        if world == 1:
+            out["quality"] = quality_leg(g, p, local_rank, args)
+            out["bubbles"] = bubbles_leg(local_rank, args)
         if world == 1 and int(st1.bundle) != 1:
             out["reference_streams"] = reference_streams_leg(g, p, local_rank, args)
         if world == 1:

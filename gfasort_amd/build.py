@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgfasort_hip.so")
-SOURCES = ["sgd_kernels_1d.hip", "sgd_kernels_nd.hip", "sgd_kernels_nd_team.hip", "index_kernels.hip", "capi.hip"]
+SOURCES = ["sgd_kernels_1d.hip", "sgd_kernels_nd.hip", "sgd_kernels_nd_team.hip", "index_kernels.hip", "capi.hip", "multi.hip"]
 HEADERS = ["sgd_device.h", "sgd_kernel_common.h", os.path.join("..", "..", "include", "gfasort_hip.h")]
 
 # -ffp-contract=off : the reference (Rust) never fuses a*b+c; device and host tables must match it

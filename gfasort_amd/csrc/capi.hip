@@ -42,6 +42,7 @@ hipError_t launch_merge_apply(double *x, double *x_prev, const float *buf, uint6
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+int gfs_set_error(int code, const std::string &msg) { return fail(code, msg); }      // for multi.hip
 #define HIPCHK(expr)                                                                           \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -373,13 +374,14 @@ static int choose_bundle(gfs_ctx *c, int dims) {
         }
     }
     c->bundle = b;
-    // Long runs (sgd_device.h run_trips): flags bits 24..31, 0 = auto.  Only the 1D team kernel at B = 64 chains trips;
-    // auto = 16 trips (runs of 1024 steps, adapted per path): the error profile over path distances of the oracle's
-    // mirror is then within a few % of reference streams on bubble graphs of 131k-2M nodes (profiles/r02).
+    // Long runs (sgd_device.h run_trips): flags bits 24..31, 0 = auto.  Only the team kernels at B = 64 chain trips;
+    // auto = 64 trips (runs of up to 4096 steps, adapted per path): the relative error of the layout, measured per octave
+    // of path distance, is then within 10 % of reference streams on bubble graphs of 0.5M and 2M nodes — below it at
+    // short distances — for the oracle's mirror and on the GPU (profiles/r02/quality_probe_long_runs.log).
     uint32_t k = (c->cfg.flags >> 24) & 0xFFu;
     if (k > 64 || (k & (k - 1))) return fail(GFS_E_ARG, "GFS_F_CHAIN: the run length in trips must be a power of two <= 64");
-    if (k == 0) k = 16;
-    c->chain = (b == 64 && dims == 0) ? k : 1;
+    if (k == 0) k = 64;
+    c->chain = b == 64 ? k : 1;                       // (nD: team kernels exist for D <= 3; checked above)
     return GFS_OK;
 }
 
@@ -484,7 +486,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     *out = nullptr;
     if (g->n_steps > (1ull << 40)) return fail(GFS_E_UNSUPPORTED, "more than 2^40 path steps");
     if (g->n_nodes > 0x7FFFFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^31-1 nodes");
-    if (g->n_paths > 0x3FFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^22-1 paths (the step records keep 22 bits for the path)");
+    if (g->n_paths > 0x7FFFFFFFull) return fail(GFS_E_UNSUPPORTED, "more than 2^31-1 paths");
     if (g->n_steps && (!g->step_node || !g->step_is_rev)) return fail(GFS_E_ARG, "null step arrays");
     if (!g->path_first_step) return fail(GFS_E_ARG, "null path_first_step");
     if (g->n_nodes && !g->node_len) return fail(GFS_E_ARG, "null node_len");
@@ -684,6 +686,7 @@ int gfs_ctx_bind_positions(gfs_ctx *c, void *device_ptr) {
     return GFS_OK;
 }
 int gfs_ctx_reset_streams(gfs_ctx *c) {
+    if (c && c->configured && !c->valid_paths) return GFS_NOTHING_TO_DO;
     if (!c || !c->d_rng) return fail(GFS_E_STATE, "context not set up");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
@@ -710,8 +713,7 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
     a.dbg = (c->cfg.flags >> 8) & 0x7Fu;             // bit 0x40 = GFS_F_DBG_WIDE_INDEX >> 8
-    if (c->cfg.flags & 0x8000u) a.dbg |= 0x100u;      // experiment: wait for a colour's adds before the next colour reads
-    if (4 * c->n_streams <= c->n_nodes && !(c->cfg.flags & GFS_F_DBG_NO_DEFER)) a.dbg |= 0x80u;   // team kernel: defer atomics by one trip
+    if (c->cfg.flags & GFS_F_DBG_NO_FUSED_TRIP) a.dbg |= 0x100u;
     a.bundle = c->bundle;
     a.chain = c->chain;
     a.n_nodes = (uint32_t)c->n_nodes;

@@ -47,7 +47,7 @@ __global__ void node_stats_kernel(const uint32_t *step_node, const uint64_t *pat
 }
 __device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t v) { return v <= 1 ? 0u : 32u - (uint32_t)__clz((int)(v - 1)); }
 
-// rec[s] = { internal node slot | NO_NODE, path | a<<22 | b<<28 | rev<<31, pos lo, pos hi } with pos = scan[s] - scan[first(path)]
+// rec[s] = { internal node slot | NO_NODE, path | rev<<31, pos lo, pos hi (23 bits) | a<<23 | b<<29 } with pos = scan[s] - scan[first(path)]
 __global__ void fill_records_kernel(const uint32_t *step_node, const uint8_t *step_is_rev, const uint32_t *perm,
                                     const uint64_t *scan, const uint64_t *path_first, uint32_t n_paths,
                                     const uint32_t *cnt, const uint32_t *rep, uint4 *rec, uint64_t n_steps) {
@@ -63,10 +63,10 @@ __global__ void fill_records_kernel(const uint32_t *step_node, const uint8_t *st
         uint32_t crowd = 0;
         if (n != 0xFFFFFFFFu) {
             const uint32_t a = ceil_log2_u32(cnt[n]), b = ceil_log2_u32(rep[n]);
-            crowd = ((a > 63u ? 63u : a) << 22) | ((b > 7u ? 7u : b) << 28);
+            crowd = ((a > 63u ? 63u : a) << 23) | ((b > 7u ? 7u : b) << 29);
         }
-        r.y = lo | crowd | ((uint32_t)(step_is_rev[s] & 1) << 31);
-        r.z = (uint32_t)pos; r.w = (uint32_t)(pos >> 32);
+        r.y = lo | ((uint32_t)(step_is_rev[s] & 1) << 31);
+        r.z = (uint32_t)pos; r.w = ((uint32_t)(pos >> 32) & 0x7FFFFFu) | crowd;
         rec[s] = r;
     }
 }

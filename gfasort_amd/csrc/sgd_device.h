@@ -83,7 +83,7 @@ struct IterConsts {
 };
 
 // device mirror of PathIndex (sgd.rs:14-31), flattened:
-//   step_rec[s]  = { node slot | NO_NODE, path id (22 bits) | crowding a<<22 b<<28 | rev<<31, pos lo, pos hi }  (16 B)
+//   step_rec[s]  = { node slot | NO_NODE, path id (31 bits) | rev<<31, pos lo, pos hi (23 bits) | crowding a<<23 b<<29 }  (16 B)
 //   path_rec[p]  = { first_step lo, step_count, (2^32-count) mod count, first_step hi } (16 B)
 struct KArgs {
     const uint4    *step_rec;
@@ -118,7 +118,9 @@ __device__ __forceinline__ uint64_t sample_step(const KArgs &a, Rng &rng) {
     return rng.uniform64(a.n_steps, a.steps_thresh);
 }
 __device__ __forceinline__ uint64_t path_first(const uint4 &pr) { return ((uint64_t)pr.w << 32) | pr.x; }
-constexpr uint32_t PATH_MASK = 0x3FFFFFu;                // step_rec.y bits 0..21: path id
+constexpr uint32_t PATH_MASK = 0x7FFFFFFFu;              // step_rec.y bits 0..30: path id (bit 31: reverse step)
+constexpr uint32_t POS_HI_MASK = 0x7FFFFFu;               // step_rec.w bits 0..22: bits 32..54 of the bp position
+__device__ __forceinline__ uint64_t rec_pos_u64(const uint4 &r) { return ((uint64_t)(r.w & POS_HI_MASK) << 32) | (uint64_t)r.z; }
 __device__ __forceinline__ uint32_t rec_path(const uint4 &r) { return r.y & PATH_MASK; }
 
 // Crowded nodes.  The kernels run ~2.5e5 terms at once where the reference runs <= 64, and a term corrects its two
@@ -127,7 +129,8 @@ __device__ __forceinline__ uint32_t rec_path(const uint4 &r) { return r.y & PATH
 // (a hub), or that a path steps on many times in a row (a tandem repeat: a run of 64 consecutive steps then hits it
 // with many lanes of the SAME trip), receives dozens of full corrections of the same error at once and the positions
 // blow up (measured: NaN on graphs with 40-fold self-loops, profiles/r01/repeat_probe.log).  Every step record
-// therefore carries two small exponents of its node, computed when the index is built (index_kernels.hip):
+// therefore carries two small exponents of its node (in the spare top bits of its position's high word: bp positions
+// stay below 2^55), computed when the index is built (index_kernels.hip):
 //   a = ceil(log2(steps on the node)),  b = ceil(log2(most visits within any 64 consecutive steps of a path)),
 // and a term's mu is scaled by 2^-k, k = max over its two nodes of max(b, a - kshift): c concurrent corrections of
 // 1/c-th size add up to about one.  kshift = floor(log2(n_steps / (2 n_streams))) + 2 puts the onset at four times
@@ -135,8 +138,8 @@ __device__ __forceinline__ uint32_t rec_path(const uint4 &r) { return r.y & PATH
 // everywhere and are bit-for-bit unaffected.  The reference has no such rule; it has no such concurrency either.
 template <bool RUNS>   // RUNS: the lanes of a wave take consecutive steps (team kernels), so tandem repeats matter
 __device__ __forceinline__ int crowd_shift(const KArgs &a, const uint4 &ra, const uint4 &rb) {
-    const int aa = (int)((ra.y >> 22) & 63u) - a.kshift, ab = (int)((rb.y >> 22) & 63u) - a.kshift;
-    const int ba = RUNS ? (int)((ra.y >> 28) & 7u) : 0, bb = RUNS ? (int)((rb.y >> 28) & 7u) : 0;
+    const int aa = (int)((ra.w >> 23) & 63u) - a.kshift, ab = (int)((rb.w >> 23) & 63u) - a.kshift;
+    const int ba = RUNS ? (int)((ra.w >> 29) & 7u) : 0, bb = RUNS ? (int)((rb.w >> 29) & 7u) : 0;
     int k = aa > ab ? aa : ab;
     const int b = ba > bb ? ba : bb;
     k = k > b ? k : b;
@@ -252,12 +255,24 @@ struct Leader {            // one sampled leader term (per lane, registers)
 // as +30 % relative error at path distances around B on large bubble graphs.  Longer blocks have proportionally fewer
 // edges: with K*B = 1024 the error profile over all path distances is within a few % of the reference's independent
 // terms, and below it at short distances (oracle mirror, profiles/r02/long_runs_mirror.log).  K adapts to the
-// leader's path: the largest power of two <= a.chain with K*B <= cnt/4, so short paths keep short runs.
+// leader's path: the largest power of two <= a.chain with K*B <= cnt/4, so short paths keep short runs.  K depends
+// on the path only, never on the jump: every leader of a path stands for the same number of terms, which keeps the
+// distribution of jumps over the TERMS what the reference's sampler makes it.
 __device__ __forceinline__ uint32_t run_trips(uint32_t chain, uint32_t bundle, uint32_t cnt) {
     const uint32_t room = cnt / (4u * bundle);
     if (room < 2u || chain < 2u) return 1u;
     const uint32_t p2 = 1u << (31 - __clz((int)room));
     return p2 < chain ? p2 : chain;
+}
+// Where trip `seg` of a run starts, in steps after the run's first step.  A long-jump run is contiguous (seg*B): that is
+// the point of it.  A leader whose jump is shorter than a trip (|jump| < B) spreads its K trips evenly over the path
+// (seg * cnt/K, wrapping): its terms are local — there is no block to shift — and contiguous short-jump runs have two
+// drawbacks: the next trip reads nodes the previous one has just added to (no-return atomics are posted: the load can
+// still see the old value), and two waves sweeping such runs along the same nodes at the same pace stay in each
+// other's way for thousands of steps (path distance 1 lost precision as K grew, profiles/r02).
+__device__ __forceinline__ uint32_t run_offset(uint32_t bundle, uint32_t cnt, uint32_t k, uint32_t ra0, uint32_t rb0, uint32_t seg) {
+    const uint32_t z = ra0 < rb0 ? rb0 - ra0 : ra0 - rb0;
+    return seg * (z < bundle ? cnt / k : bundle);
 }
 
 template <bool LDS_TABLES>
@@ -302,7 +317,7 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
         // C3: 0.30 -> 0.26 atomic requests per update, 68 -> 74 G updates/s.
         const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0;
         const int64_t Bn = (int64_t)a.bundle;
-        const int64_t Rn = Bn * (int64_t)run_trips(a.chain, a.bundle, L.cnt);         // steps of the whole run
+        const int64_t Rn = Bn * (int64_t)run_trips(a.chain, a.bundle, L.cnt);         // steps of the whole run (|jump| >= B + 8: contiguous)
         if (jump >= Bn + 8 || jump <= -(Bn + 8)) {
             const int64_t A = a.bundle < 8u ? (int64_t)a.bundle : 8;               // runs shorter than a line: align to the run length
             const uint32_t sh = r0.x & (uint32_t)(A - 1);
@@ -331,29 +346,31 @@ __device__ __forceinline__ bool two_colour(uint32_t ok, uint32_t cnt, uint32_t r
     return s < (int64_t)B && s > -(int64_t)B;                                          // s != 0 since ok & 1
 }
 
-// Expand leader values (already broadcast to this lane) into this lane's own term for trip `seg` of the run (0 .. K-1,
-// run_trips) and colour `colour` (0 for every leader; 1 only for two_colour leaders).  Returns false when the lane
-// does not act in this trip.
+// Expand leader values (already broadcast to this lane) into this lane's own term for the trip that starts `off` steps
+// after the run's first step (run_offset) and colour `colour` (0 for every leader; 1 only for two_colour leaders).
+// Returns false when the lane does not act in this trip.
 template <int B>
 __device__ __forceinline__ bool expand_run(uint32_t ok, uint64_t first, uint32_t cnt, uint32_t ra0, uint32_t rb0,
-                                           int sub, uint32_t colour, uint32_t seg, uint64_t &sa, uint64_t &sb) {
+                                           int sub, uint32_t colour, uint32_t off, uint64_t &sa, uint64_t &sb) {
     if (!(ok & 1u)) return false;
     if (ok & 2u) {                                                                     // both runs line-aligned blocks inside the path
         if (colour) return false;
-        sa = first + ra0 + seg * (uint32_t)B + (uint32_t)sub;
-        sb = first + rb0 + seg * (uint32_t)B + (((uint32_t)sub + ((ok >> 2) & 7u)) & (uint32_t)(B - 1));
+        sa = first + ra0 + off + (uint32_t)sub;
+        sb = first + rb0 + off + (((uint32_t)sub + ((ok >> 2) & 7u)) & (uint32_t)(B - 1));
         return true;
     }
     uint32_t ra_l = ra0, rb_l = rb0;
-    const uint32_t l = seg * (uint32_t)B + (uint32_t)sub;                              // place in the run
+    const uint32_t l = off + (uint32_t)sub;                                            // place in the run
     if (l != 0 || colour) {
         if (cnt < 2u * B) return false;                                                // short path: leader only
         const int64_t shift = (int64_t)rb0 - (int64_t)ra0;
         const uint32_t z = (uint32_t)(shift < 0 ? -shift : shift);
         if (z < (uint32_t)B) { if (((l / z) & 1u) != colour) return false; }           // node-disjoint lanes of this colour
         else if (colour) return false;
-        ra_l = ra0 + l;
-        if (ra_l >= cnt) ra_l -= cnt;                                                  // wrap to the path start (run <= cnt/2 steps)
+        uint64_t ra_w = (uint64_t)ra0 + l;                                             // wrap to the path start (l < cnt + B)
+        if (ra_w >= cnt) ra_w -= cnt;
+        if (ra_w >= cnt) ra_w -= cnt;
+        ra_l = (uint32_t)ra_w;
         int64_t t = (int64_t)ra_l + shift;
         if (t < 0 || t > (int64_t)cnt - 1) {
             // partner outside the path.  A step this close to a path end samples into the path in
@@ -371,7 +388,7 @@ __device__ __forceinline__ bool expand_run(uint32_t ok, uint64_t first, uint32_t
 }
 
 __device__ __forceinline__ double rec_pos(const uint4 &r) {
-    return (double)(((uint64_t)r.w << 32) | (uint64_t)r.z);
+    return (double)rec_pos_u64(r);
 }
 
 }  // namespace gfs

@@ -87,14 +87,21 @@ __device__ __forceinline__ uint64_t bcast_first(const Leader &L, int leader_lane
 // therefore handed to the resting lane that sits on its node, and ONE instruction carries every add of the trip;
 // only partners beyond the run's ends are added by a second, nearly empty one.  Returns the signed jump, or 0.
 template <int B>
-__device__ __forceinline__ int merged_trip_shift(uint32_t ok, uint32_t cnt, uint32_t ra0, uint32_t rb0, uint32_t seg) {
+__device__ __forceinline__ int merged_trip_shift(uint32_t ok, uint32_t cnt, uint32_t ra0, uint32_t rb0, uint32_t off) {
     if (B != 64 || (ok & 3u) != 1u || cnt < 128u) return 0;
     const int64_t s = (int64_t)rb0 - (int64_t)ra0;
     if (s == 0 || s >= 64 || s <= -64) return 0;
-    const uint64_t base = (uint64_t)ra0 + 64u * (uint64_t)seg;                         // first step of this trip
+    uint64_t base = (uint64_t)ra0 + (uint64_t)off;                                     // first step of this trip
+    if (base >= cnt) base -= cnt;
     if (base + 64u > cnt) return 0;                                                    // the trip would wrap
     if (s > 0 ? base + 63u + (uint64_t)s > (uint64_t)cnt - 1u : (int64_t)base + s < 0) return 0;
     return (int)s;
+}
+// first step of the trip that merged_trip_shift accepted (rank in the path)
+__device__ __forceinline__ uint32_t merged_trip_base(uint32_t cnt, uint32_t ra0, uint32_t off) {
+    uint64_t base = (uint64_t)ra0 + (uint64_t)off;
+    if (base >= cnt) base -= cnt;
+    return (uint32_t)base;
 }
 
 

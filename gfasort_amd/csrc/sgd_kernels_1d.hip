@@ -66,19 +66,17 @@ __global__ void sgd1d_kernel(const KArgs a) {
 // K1b: 1D team kernel — bundled ("run") sampling (sgd_device.h).  A wave is a team:
 //   pass   : all 64 lanes sample one leader term each from their own reference streams — the
 //            Zipf/f64 arithmetic runs at full SIMD width instead of on one lane per bundle;
-//   trips  : B trips execute the 64 leaders as 64/B runs of B lanes.  The records of trip t+1
-//            are requested before trip t is consumed, and (DEFER) the atomics of trip t are
-//            issued behind the position loads of trip t+1, so a trip exposes one memory round
-//            trip (its position loads) instead of three and never waits for its own atomics
-//            (vmcnt retires in order: an atomic issued before a load would be waited for).
-//            Deferring doubles the window in which a wave reads positions it is about to
-//            change; the host enables it only when in-flight terms are few relative to the
-//            number of nodes (4*n_streams <= n_nodes) — on small graphs with many streams the
-//            extra staleness pushed the concurrent corrections per node past stability.
+//   trips  : the leaders are executed one slot after the other, each as 64/B runs of B lanes.  With B = 64 a
+//            leader's run extends over K consecutive trips (LONG RUNS, sgd_device.h run_trips); a leader whose
+//            jump is shorter than a trip runs for one trip only and both of its colours (two_colour) are computed in
+//            that trip (fused_trip), or in two trips where it touches a path end.  The records of the next
+//            trip are requested before the current one is consumed, so a trip exposes one memory round trip
+//            (its position loads); its adds are issued at once and never waited for by themselves.
+//            (Round 1 issued a trip's adds one trip late, behind the next trip's loads; with long runs — whose
+//            next trip touches the neighbouring lines — that was slower, 66.8 vs 73.4 G updates/s on C3, and it
+//            let a wave read positions it was about to change: profiles/r02/quality_probe_defer.log.)
 // The quota is per WAVE with a rank cut-off in the last trip: an iteration performs exactly its
-// number of updates; the trips of a pass left over when the quota fills serve the next iteration
-// (TeamState).  Runs are line-aligned (sgd_device.h sample_leader) and short-jump trips issue all
-// their adds in one instruction (sgd_kernel_common.h merged_trip_shift).
+// number of updates; what is left of a pass when the quota fills serves the next iteration (TeamState).
 // ------------------------------------------------------------------------------------------
 // Per-wave state that survives from one iteration to the next inside a launch.
 struct TeamState {
@@ -90,19 +88,18 @@ struct TeamState {
     Leader L = {0, 0, 0, 0, 0, 0};
     uint32_t left = 0, cool = 0, colour = 0, seg = 0;   // seg: next trip of the current slot's run (sgd_device.h run_trips)
     uint32_t done = 0, att = 0, ntr = 0;
-    // deferred atomics of the previous trip: up to two adds per lane (normally -r to node i and +r to node j)
-    bool p1f = false, p2f = false; uint32_t p1s = 0, p2s = 0; double p1v = 0.0, p2v = 0.0;
 };
 
 // One trip = (slot t of the pass, trip seg of its run, colour): what every lane needs to execute it.
 struct Trip {
     uint64_t sa = 0, sb = 0;
     uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-    bool valid = false;
+    bool valid = false;        // this lane acts in the trip (fused trip: this lane's partner lies beyond the trip's 64 steps)
     int mshift = 0;            // != 0: merged short-jump trip (sgd_kernel_common.h merged_trip_shift)
     bool two = false;          // wave-uniform: some run of this slot has a second colour
-    bool near = false;         // wave-uniform: the run's next trip reads nodes this trip updates (|jump| < 2B)
+    bool fused = false;        // wave-uniform: both colours of a short-jump run in ONE trip (fused_trip)
     uint32_t k = 1;            // wave-uniform: trips of this slot's run (long runs: B = 64 only)
+    uint32_t off = 0;          // wave-uniform: this trip starts `off` steps after the run's first step (run_offset)
 };
 
 template <int B>
@@ -110,20 +107,113 @@ __device__ __forceinline__ void expand_trip(const KArgs &a, const Leader &L, int
     constexpr int RUNS = 64 / B;
     const int ll = t * RUNS + q;
     const uint32_t ok = bcast<B>(L.ok, ll), cnt = bcast<B>(L.cnt, ll), ra0 = bcast<B>(L.ra0, ll), rb0 = bcast<B>(L.rb0, ll);
-    tr.valid = expand_run<B>(ok, bcast_first<B>(L, ll), cnt, ra0, rb0, sub, colour, seg, tr.sa, tr.sb);
-    tr.mshift = merged_trip_shift<B>(ok, cnt, ra0, rb0, seg);
-    const bool two = !(a.dbg & 0x08u) && two_colour<B>(ok, cnt, ra0, rb0);
-    tr.two = B == 64 ? two : (__any(two) != 0);                       // B = 64: the leader is wave-uniform already
+    const uint64_t first = bcast_first<B>(L, ll);
     // long runs only where the whole wave follows one leader; a leader the reference rejected takes one (empty) trip
     tr.k = (B == 64 && (ok & 1u) && cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, cnt) : 1u;
-    const int64_t s = (int64_t)rb0 - (int64_t)ra0;
-    tr.near = B == 64 && s < 2 * B && s > -2 * B;
+    tr.off = B == 64 ? run_offset((uint32_t)B, cnt, tr.k, ra0, rb0, seg) : 0u;
+    tr.mshift = merged_trip_shift<B>(ok, cnt, ra0, rb0, tr.off);
+    const bool two = !(a.dbg & 0x08u) && two_colour<B>(ok, cnt, ra0, rb0);
+    tr.two = B == 64 ? two : (__any(two) != 0);                       // B = 64: the leader is wave-uniform already
     tr.ra = make_uint4(0, 0, 0, 0); tr.rb = make_uint4(0, 0, 0, 0);
+    tr.fused = B == 64 && tr.mshift != 0 && colour == 0 && two && !(a.dbg & 0x100u);
+    if (tr.fused) {
+        // every lane takes its own step of the trip and its partner's record (the partners inside the trip are the other
+        // lanes' own steps: the same lines, no extra traffic; merged_trip_shift guarantees all of them lie in the path)
+        const int dst = sub + tr.mshift;
+        tr.sa = first + merged_trip_base(cnt, ra0, tr.off) + (uint32_t)sub;
+        tr.sb = (uint64_t)((int64_t)tr.sa + tr.mshift);
+        tr.valid = dst < 0 || dst > 63;
+        tr.ra = a.step_rec[tr.sa];
+        tr.rb = a.step_rec[tr.sb];
+        return;
+    }
+    tr.valid = expand_run<B>(ok, first, cnt, ra0, rb0, sub, colour, tr.off, tr.sa, tr.sb);
     if (tr.valid) { tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb]; }
 }
 
+// The term arithmetic of sgd.rs:518-571 on values already in registers; returns r_x.
+__device__ __forceinline__ double term_move(const KArgs &a, double term_dist, double xi, double xj, int crowd) {
+    double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd);          // :518-520
+    double dx = xi - xj;                                                               // :543
+    if (dx == 0.0) dx = 1e-9;                                                          // :546-548
+    double mag = fabs(dx);                                                             // :551
+    double delta = mu * (mag - term_dist) / 2.0;                                       // :552
+    double r = delta / mag;                                                            // :570
+    return r * dx;                                                                     // :571
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src, 64); }
+
+// FUSED short-jump trip (B = 64, |jump| = z < 64, the run's 64 steps and all their partners inside the path).
+// The run's 64 terms (l, l+s) form two node-disjoint colours (two_colour).  As two trips, each colour loads the records
+// and positions of half the lanes and of their partners — which are the OTHER colour's lanes — and the second colour
+// reads what the first one wrote.  Here every lane loads its own record and position once; partners inside the run are
+// read from the lane that holds them (wave shuffles), colour 1 computes on the positions colour 0 has just produced in
+// registers (bit for bit what it would read back from memory when no other wave interferes), and each colour issues one
+// coalesced add per lane.  Same terms, same arithmetic, same order as the two trips.  What it buys is not speed (it is
+// 2-5 % slower than two trips) but precision under concurrency: both colours see ONE snapshot of the run's 64 nodes and
+// land within one memory round trip, instead of exposing the run to the other ~4 000 waves for two.  At one stream per
+// two nodes (525k-node bubble graph) the relative error at path distance 1 is 0.200 against 0.248 with two trips
+// (reference streams: 0.194; profiles/r02/quality_probe_long_runs.log).  Returns false when the wave's quota filled
+// before the second colour: the caller leaves that colour to the next iteration as a generic trip.
+template <bool ATOMIC_LOADS, bool TRACE>
+__device__ __forceinline__ bool fused_trip(const KArgs &a, TeamState &ts, const Trip &cur, const int lane,
+                                           const uint32_t tid, const uint64_t wave_quota, uint64_t &wave_done) {
+    double *x = a.x;
+    const int s = cur.mshift, z = s < 0 ? -s : s;
+    const int dst = lane + s, src = lane - s;                          // my partner's lane; the lane whose partner I am
+    const bool out = cur.valid;                                        // partner beyond the trip's 64 steps
+    const int dstc = out ? lane : dst, srcc = (src < 0 || src > 63) ? lane : src;
+    const uint32_t grp = ((cur.off + (uint32_t)lane) / (uint32_t)z) & 1u;
+    const uint32_t node = cur.ra.x, pnode = cur.rb.x;
+    double xo = 0.0, xp = 0.0;                                         // my position; my partner's when it is beyond the trip
+    if (!(a.dbg & 2u)) {
+        if (node != 0xFFFFFFFFu) xo = load_pos<ATOMIC_LOADS>(x + node);
+        if (out && pnode != 0xFFFFFFFFu) xp = load_pos<ATOMIC_LOADS>(x + pnode);       // (partners inside: from their lanes)
+    } else { xo = (double)node; xp = (double)pnode; }
+    const double term_dist = fabs(rec_pos(cur.ra) - rec_pos(cur.rb));                  // sgd.rs:513
+    const int crowd = crowd_shift<true>(a, cur.ra, cur.rb);
+    const bool term_ok = term_dist != 0.0 && node != 0xFFFFFFFFu && pnode != 0xFFFFFFFFu;   // :514, :525-538
+#pragma unroll
+    for (uint32_t colour = 0; colour < 2u; ++colour) {
+        ++ts.att;
+        bool valid = term_ok && grp == colour;
+        const unsigned long long vmask = __ballot(valid);
+        const uint64_t remaining = wave_quota - wave_done;
+        const uint32_t nvalid = (uint32_t)__popcll(vmask);
+        if (valid && nvalid > remaining) valid = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull)) < remaining;
+        wave_done += nvalid < remaining ? nvalid : remaining;
+        const double xpart_in = shfl_f64(xo, dstc);                    // partner's CURRENT position (colour 0's result for colour 1)
+        const double xj = out ? xp : xpart_in;
+        double r_x = 0.0;
+        if (valid) {
+            r_x = term_move(a, term_dist, xo, xj, crowd);
+            ++ts.done;                                                                 // :579
+            if (TRACE) {
+                if (ts.ntr < a.trace_per_stream) {
+                    TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ts.ntr;
+                    tt->i = node; tt->j = pnode; tt->d = term_dist;
+                    ++ts.ntr;
+                }
+            }
+        }
+        // the +r of the lane whose partner I am
+        const double rv = shfl_f64(r_x, srcc);
+        const bool recv = src >= 0 && src <= 63 && __shfl((int)valid, srcc, 64) != 0;
+        // a lane acts or receives in a colour, never both (its group's parity decides)
+        if (valid) xo = xo - r_x;                                                      // :575  x[i] - r_x
+        if (recv) xo = xo + rv;                                                        // :576  x[j] + r_x
+        if (!(a.dbg & 1u)) {
+            if (valid) add_pos(x + node, -r_x); else if (recv) add_pos(x + node, rv);
+            if (valid && out) add_pos(x + pnode, r_x);
+        }
+        if (colour == 0 && wave_done >= wave_quota) return false;
+    }
+    return true;
+}
+
 // One SGD iteration of one wave: passes and trips until the wave's quota is filled.
-template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+template <int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
                                                TeamState &ts, const uint32_t tid, const uint64_t wave_quota) {
     const int lane = threadIdx.x & 63;
@@ -144,15 +234,26 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
         Trip cur;
         expand_trip<B>(a, L, t, seg, colour, sub, q, cur);             // expand and request the records of the first trip
         for (;;) {
-            // the trip after this one: this trip's second colour, else the run's next trip, else the next slot;
-            // request its records now
+            // the trip after this one: this trip's second colour (unless fused into it), else the run's next trip, else the
+            // next slot; request its records now
             int t_n = t; uint32_t colour_n = 0u, seg_n = seg;
-            if (colour == 0 && cur.two) colour_n = 1u;
+            if (colour == 0 && cur.two && !cur.fused) colour_n = 1u;
             else if (seg + 1u < cur.k) seg_n = seg + 1u;
             else { t_n = t + 1; seg_n = 0u; }
             const bool have_n = t_n < B;
             Trip nxt;
             if (have_n) expand_trip<B>(a, L, t_n, seg_n, colour_n, sub, q, nxt);
+            if (B == 64 && cur.fused) {
+                if (!fused_trip<ATOMIC_LOADS, TRACE>(a, ts, cur, lane, tid, wave_quota, wave_done)) {
+                    ts.colour = 1u; ts.seg = seg;                      // quota filled between the colours: the second one is
+                    break;                                             // the next iteration's first trip (generic form)
+                }
+                ts.colour = 0u; ts.seg = seg_n;
+                if (t_n != t) --ts.left;
+                if (wave_done >= wave_quota || !have_n) break;
+                cur = nxt; t = t_n; colour = colour_n; seg = seg_n;
+                continue;
+            }
             // consume the current trip
             ++ts.att;
             ts.colour = colour_n; ts.seg = seg_n;
@@ -175,36 +276,14 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
                 valid = rank < remaining;
             }
             wave_done += nvalid < remaining ? nvalid : remaining;
-            // A second-colour trip reads the nodes its first colour has just moved, and so does the next trip of a run
-            // whose jump is shorter than two trips: those adds go out first.
-            if (DEFER && (colour != 0 || (seg != 0 && cur.near)) && !(a.dbg & 1u)) {
-                if (ts.p1f) add_pos(x + ts.p1s, ts.p1v);
-                if (ts.p2f) add_pos(x + ts.p2s, ts.p2v);
-                ts.p1f = false; ts.p2f = false;
-            }
-            if ((a.dbg & 0x100u) && (colour != 0 || (seg != 0 && cur.near))) __builtin_amdgcn_s_waitcnt(0);   // experiment
             double xi = 0.0, xj = 0.0;
             if (valid) {
                 if (a.dbg & 2u) { xi = (double)i; xj = (double)j; }                    // ablation: no position loads
                 else { xi = load_pos<ATOMIC_LOADS>(x + i); xj = load_pos<ATOMIC_LOADS>(x + j); }   // :541-542
             }
-            if (DEFER) {                                                               // the previous trip's :575-576
-                if (a.dbg & 1u) { asm volatile("" :: "v"(ts.p1v), "v"(ts.p1s), "v"(ts.p2v), "v"(ts.p2s)); }   // ablation: no atomics
-                else {
-                    if (ts.p1f) add_pos(x + ts.p1s, ts.p1v);
-                    if (ts.p2f) add_pos(x + ts.p2s, ts.p2v);
-                }
-                ts.p1f = false; ts.p2f = false;
-            }
             double r_x = 0.0;
             if (valid) {
-                double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd_shift<true>(a, ra, rb));                   // :518-520
-                double dx = xi - xj;                                                   // :543
-                if (dx == 0.0) dx = 1e-9;                                              // :546-548
-                double mag = fabs(dx);                                                 // :551
-                double delta = mu * (mag - term_dist) / 2.0;                           // :552
-                double r = delta / mag;                                                // :570
-                r_x = r * dx;                                                          // :571
+                r_x = term_move(a, term_dist, xi, xj, crowd_shift<true>(a, ra, rb));   // :518-571
                 ++ts.done;                                                             // :579
                 if (TRACE) {
                     if (ts.ntr < a.trace_per_stream) {
@@ -225,13 +304,12 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
                 const double rv = __shfl(r_x, srcc, 64);
                 const uint32_t js = (uint32_t)__shfl((int)j, srcc, 64);
                 const int vs = __shfl((int)valid, srcc, 64);
-                const bool resting = (((seg * 64u + (uint32_t)lane) / (uint32_t)z) & 1u) != colour;
+                const bool resting = (((cur.off + (uint32_t)lane) / (uint32_t)z) & 1u) != colour;
                 if (resting && src >= 0 && src < 64 && vs) { o1f = true; o1s = js; o1v = rv; }
                 const int dst = lane + mshift;                                         // where my own partner sits
                 o2f = valid && (dst < 0 || dst > 63);                                  // beyond the run: add it myself
             }
-            if (DEFER) { ts.p1f = o1f; ts.p1s = o1s; ts.p1v = o1v; ts.p2f = o2f; ts.p2s = o2s; ts.p2v = o2v; }
-            else if (!(a.dbg & 1u)) {
+            if (!(a.dbg & 1u)) {                                                       // (ablation: no atomics)
                 if (o1f) add_pos(x + o1s, o1v);
                 if (o2f) add_pos(x + o2s, o2v);
             }
@@ -242,11 +320,6 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
     }
 }
 
-__device__ __forceinline__ void flush_pending(const KArgs &a, TeamState &ts) {
-    if (ts.p1f) add_pos(a.x + ts.p1s, ts.p1v);
-    if (ts.p2f) add_pos(a.x + ts.p2s, ts.p2v);
-    ts.p1f = false; ts.p2f = false;
-}
 __device__ __forceinline__ void load_pass(const KArgs &a, uint32_t tid, TeamState &ts) {
     if (!a.lead) return;
     const uint64_t T = a.n_streams;
@@ -271,7 +344,7 @@ __device__ __forceinline__ uint64_t wave_quota_of(const KArgs &a, uint32_t tid) 
     return wq;
 }
 
-template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+template <int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __global__ void sgd1d_team_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
@@ -283,8 +356,7 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
     ts.rng.s0 = a.rng[tid]; ts.rng.s1 = a.rng[T + tid]; ts.rng.s2 = a.rng[2 * T + tid]; ts.rng.s3 = a.rng[3 * T + tid];
     ts.ntr = TRACE ? a.trace_cnt[tid] : 0;
     load_pass(a, tid, ts);
-    team_iteration<B, DEFER, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wave_quota_of(a, tid));
-    flush_pending(a, ts);
+    team_iteration<B, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wave_quota_of(a, tid));
     a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;
     if (TRACE) a.trace_cnt[tid] = ts.ntr;
     store_pass(a, tid, ts);
@@ -296,7 +368,7 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
 // iteration's constants.  No grid barrier separates iterations — the reference's boundaries are looser
 // still (a 1 ms polling thread, sgd.rs:366-403) — but every iteration still applies exactly
 // min_term_updates updates with its own eta/theta.  Saves the per-launch ramp, tail and RNG round trip.
-template <int B, bool DEFER, bool LDS_TABLES, bool ATOMIC_LOADS>
+template <int B, bool LDS_TABLES, bool ATOMIC_LOADS>
 __global__ void sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
@@ -311,9 +383,7 @@ __global__ void sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, c
     load_pass(a, tid, ts);
     for (uint32_t k = 0; k < n_iters; ++k) {
         a.it = its[k];                                                // wave-uniform: scalar loads
-        team_iteration<B, DEFER, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq);
-        // same flush point as the per-iteration kernel: a single wave gives bit-identical results either way
-        if (DEFER) flush_pending(a, ts);
+        team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq);
     }
     a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;
     store_pass(a, tid, ts);
@@ -369,14 +439,8 @@ static hipError_t launch_1d_t(const KArgs &a, bool trace, dim3 grid, dim3 block,
 }
 template <int B, bool L, bool A>
 static hipError_t launch_1db_t(const KArgs &a, bool trace, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    const bool defer = (a.dbg & 0x80u) != 0;          // host decision, see capi.hip
-    if (trace) {                                      // debug trace: one variant (agent-scope loads, no deferral)
-        hipLaunchKernelGGL((sgd1d_team_kernel<B, false, L, true, true>), grid, block, lds, st, a);
-    } else if (defer) {
-        hipLaunchKernelGGL((sgd1d_team_kernel<B, true, L, A, false>), grid, block, lds, st, a);
-    } else {
-        hipLaunchKernelGGL((sgd1d_team_kernel<B, false, L, A, false>), grid, block, lds, st, a);
-    }
+    if (trace) hipLaunchKernelGGL((sgd1d_team_kernel<B, L, true, true>), grid, block, lds, st, a);   // debug trace: agent-scope loads
+    else       hipLaunchKernelGGL((sgd1d_team_kernel<B, L, A, false>), grid, block, lds, st, a);
     return hipGetLastError();
 }
 template <int B>
@@ -390,14 +454,8 @@ static hipError_t launch_1db(const KArgs &a, bool lds_tables, bool atomic_loads,
 template <int B>
 static hipError_t launch_1d_fused_b(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
                                     dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    const bool defer = (a.dbg & 0x80u) != 0;
-    if (lds_tables) {
-        if (defer) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, true, true>), grid, block, lds, st, a, d_its, n_iters);
-        else       hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, true, true>), grid, block, lds, st, a, d_its, n_iters);
-    } else {
-        if (defer) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, false, true>), grid, block, 0, st, a, d_its, n_iters);
-        else       hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, false, true>), grid, block, 0, st, a, d_its, n_iters);
-    }
+    if (lds_tables) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, true>), grid, block, lds, st, a, d_its, n_iters);
+    else            hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, true>), grid, block, 0, st, a, d_its, n_iters);
     return hipGetLastError();
 }
 // fused range of iterations; only for the team kernel with its widest bundles (what the auto policy picks

@@ -35,10 +35,10 @@ __global__ void sgdnd_kernel(const KArgs a) {
             const uint64_t first = path_first(path_tab[path]);
             const uint64_t last_step = first + cnt - 1u;
             const uint64_t plen = a.path_len[path];
-            uint64_t pa = ((uint64_t)ra.w << 32) | ra.z, pb = ((uint64_t)rb.w << 32) | rb.z;
+            uint64_t pa = rec_pos_u64(ra), pb = rec_pos_u64(rb);
             uint64_t na, nb;                       // position of the following step / path end
-            if (sa == last_step) na = plen; else { uint4 n = a.step_rec[sa + 1u]; na = ((uint64_t)n.w << 32) | n.z; }
-            if (sb == last_step) nb = plen; else { uint4 n = a.step_rec[sb + 1u]; nb = ((uint64_t)n.w << 32) | n.z; }
+            if (sa == last_step) na = plen; else { uint4 n = a.step_rec[sa + 1u]; na = rec_pos_u64(n); }
+            if (sb == last_step) nb = plen; else { uint4 n = a.step_rec[sb + 1u]; nb = rec_pos_u64(n); }
             double pos_a = (double)pa, pos_b = (double)pb;                             // sgd.rs:1047-1048
             const double len_i = (double)(na - pa), len_j = (double)(nb - pb);        // :1051-1058
             const bool rev_i = (ra.y >> 31) != 0, rev_j = (rb.y >> 31) != 0;           // :1061,1070

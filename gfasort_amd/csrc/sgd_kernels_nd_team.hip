@@ -18,6 +18,37 @@ hipError_t launch_nd_ref(int dims, const KArgs &a, bool lds_tables, bool atomic_
 // binds this kernel).  Node lengths come from the following step record as in K2.  Atomics are
 // issued in the trip that computes them (no deferral).
 // ------------------------------------------------------------------------------------------
+// One trip = (slot t of the pass, trip seg of its run, colour) — as in K1b (sgd_kernels_1d.hip): long runs for B = 64
+// (sgd_device.h run_trips) and two colours for jumps shorter than the run (two_colour).
+struct TripND {
+    uint64_t sa = 0, sb = 0, first = 0;
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0), na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
+    uint32_t cnt = 0, flips = 0, k = 1, off = 0;
+    bool valid = false, two = false;
+    int mshift = 0;
+};
+
+template <int B>
+__device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, uint32_t lflips, int t, uint32_t seg, uint32_t colour,
+                                               int sub, int q, TripND &tr) {
+    constexpr int RUNS = 64 / B;
+    const int ll = t * RUNS + q;
+    const uint32_t ok = bcast<B>(L.ok, ll), ra0 = bcast<B>(L.ra0, ll), rb0 = bcast<B>(L.rb0, ll);
+    tr.first = bcast_first<B>(L, ll); tr.cnt = bcast<B>(L.cnt, ll); tr.flips = bcast<B>(lflips, ll);
+    tr.k = (B == 64 && (ok & 1u) && tr.cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, tr.cnt) : 1u;
+    tr.off = B == 64 ? run_offset((uint32_t)B, tr.cnt, tr.k, ra0, rb0, seg) : 0u;
+    tr.valid = expand_run<B>(ok, tr.first, tr.cnt, ra0, rb0, sub, colour, tr.off, tr.sa, tr.sb);
+    tr.mshift = merged_trip_shift<B>(ok, tr.cnt, ra0, rb0, tr.off);
+    const bool two = !(a.dbg & 0x08u) && two_colour<B>(ok, tr.cnt, ra0, rb0);
+    tr.two = B == 64 ? two : (__any(two) != 0);
+    tr.ra = make_uint4(0, 0, 0, 0); tr.rb = tr.ra; tr.na = tr.ra; tr.nb = tr.ra;
+    if (tr.valid) {
+        tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb];
+        tr.na = a.step_rec[tr.sa + 1u < a.n_steps ? tr.sa + 1u : tr.sa];
+        tr.nb = a.step_rec[tr.sb + 1u < a.n_steps ? tr.sb + 1u : tr.sb];
+    }
+}
+
 template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __global__ void sgdnd_team_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -29,7 +60,6 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
     const int lane = threadIdx.x & 63;
     const int sub = lane & (B - 1);
     const int q = lane / B;
-    constexpr int RUNS = 64 / B;
     const uint64_t T = a.n_streams;
     Rng rng;
     rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid];
@@ -45,31 +75,23 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
         ++passes;
         const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
         const uint32_t lflips = rng.flip() | (rng.flip() << 1);            // the run's end flips: bit 0 = a, bit 1 = b
-        uint64_t sa = 0, sb = 0;
-        uint64_t first = bcast_first<B>(L, q); uint32_t cnt = bcast<B>(L.cnt, q);
-        uint32_t flips = bcast<B>(lflips, q);
-        bool valid = expand_run<B>(bcast<B>(L.ok, q), first, cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), sub, 0u, 0u, sa, sb);
-        int mshift = merged_trip_shift<B>(bcast<B>(L.ok, q), cnt, bcast<B>(L.ra0, q), bcast<B>(L.rb0, q), 0u);   // see sgd_kernel_common.h
-        uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, na = ra, nb = ra;
-        if (valid) {
-            ra = a.step_rec[sa]; rb = a.step_rec[sb];
-            na = a.step_rec[sa + 1u < a.n_steps ? sa + 1u : sa]; nb = a.step_rec[sb + 1u < a.n_steps ? sb + 1u : sb];
-        }
-#pragma unroll 2
-        for (int t = 0; t < B; ++t) {
-            uint64_t sa_n = 0, sb_n = 0, first_n = 0; uint32_t cnt_n = 0, flips_n = 0; bool valid_n = false; int mshift_n = 0;
-            uint4 ra_n = make_uint4(0, 0, 0, 0), rb_n = ra_n, na_n = ra_n, nb_n = ra_n;
-            if (t + 1 < B) {
-                const int ll = (t + 1) * RUNS + q;
-                first_n = bcast_first<B>(L, ll); cnt_n = bcast<B>(L.cnt, ll); flips_n = bcast<B>(lflips, ll);
-                valid_n = expand_run<B>(bcast<B>(L.ok, ll), first_n, cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), sub, 0u, 0u, sa_n, sb_n);
-                mshift_n = merged_trip_shift<B>(bcast<B>(L.ok, ll), cnt_n, bcast<B>(L.ra0, ll), bcast<B>(L.rb0, ll), 0u);
-                if (valid_n) {
-                    ra_n = a.step_rec[sa_n]; rb_n = a.step_rec[sb_n];
-                    na_n = a.step_rec[sa_n + 1u < a.n_steps ? sa_n + 1u : sa_n];
-                    nb_n = a.step_rec[sb_n + 1u < a.n_steps ? sb_n + 1u : sb_n];
-                }
-            }
+        int t = 0; uint32_t seg = 0, colour = 0;
+        TripND cur;
+        expand_trip_nd<B>(a, L, lflips, t, seg, colour, sub, q, cur);
+        for (;;) {
+            // the trip after this one (second colour, next trip of the run, next slot): request its records now
+            int t_n = t; uint32_t colour_n = 0u, seg_n = seg;
+            if (colour == 0 && cur.two) colour_n = 1u;
+            else if (seg + 1u < cur.k) seg_n = seg + 1u;
+            else { t_n = t + 1; seg_n = 0u; }
+            const bool have_n = t_n < B;
+            TripND nxt;
+            if (have_n) expand_trip_nd<B>(a, L, lflips, t_n, seg_n, colour_n, sub, q, nxt);
+            bool valid = cur.valid;
+            const uint4 ra = cur.ra, rb = cur.rb, na = cur.na, nb = cur.nb;
+            const uint64_t sa = cur.sa, sb = cur.sb, first = cur.first;
+            const uint32_t cnt = cur.cnt, flips = cur.flips;
+            const int mshift = cur.mshift;
             ++att;
             double term_dist = 0.0;
             uint64_t idx_i = 0, idx_j = 0;
@@ -77,9 +99,9 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
             if (valid) {
                 const uint64_t last_step = first + cnt - 1u;
                 const uint64_t plen = a.path_len[rec_path(ra)];
-                const uint64_t pa = ((uint64_t)ra.w << 32) | ra.z, pb = ((uint64_t)rb.w << 32) | rb.z;
-                const uint64_t ea = sa == last_step ? plen : (((uint64_t)na.w << 32) | na.z);
-                const uint64_t eb = sb == last_step ? plen : (((uint64_t)nb.w << 32) | nb.z);
+                const uint64_t pa = rec_pos_u64(ra), pb = rec_pos_u64(rb);
+                const uint64_t ea = sa == last_step ? plen : rec_pos_u64(na);
+                const uint64_t eb = sb == last_step ? plen : rec_pos_u64(nb);
                 double pos_a = (double)pa, pos_b = (double)pb;                         // sgd.rs:1047-1048
                 const double len_i = (double)(ea - pa), len_j = (double)(eb - pb);     // :1051-1058
                 const bool rev_i = (ra.y >> 31) != 0, rev_j = (rb.y >> 31) != 0;
@@ -163,7 +185,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                     double rs[D];
 #pragma unroll
                     for (int k = 0; k < D; ++k) rs[k] = __shfl(upd_r[k], srcc, 64);
-                    const bool resting = (((uint32_t)lane / (uint32_t)z) & 1u) != 0u;
+                    const bool resting = (((cur.off + (uint32_t)lane) / (uint32_t)z) & 1u) != colour;
                     if (resting && src >= 0 && src < 64 && fjs) {
                         pA = pjs; fA = 1;
 #pragma unroll
@@ -190,8 +212,9 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                     }
                 }
             }
-            if (wave_done >= wave_quota) break;
-            ra = ra_n; rb = rb_n; na = na_n; nb = nb_n; sa = sa_n; sb = sb_n; valid = valid_n; first = first_n; cnt = cnt_n; flips = flips_n; mshift = mshift_n;
+            if (wave_done >= wave_quota) break;                        // what is left of the pass is dropped (no carry-over in nD)
+            if (!have_n) break;
+            cur = nxt; t = t_n; colour = colour_n; seg = seg_n;
         }
     }
     a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;

@@ -1,100 +1,64 @@
-"""Multi-GPU SGD: paths sharded over ranks, positions replicated, one all-reduce of position
-deltas per iteration (RCCL over xGMI when the tensors live on GPUs).
+"""Multi-GPU SGD: paths sharded over ranks, one process per GPU, replicas merged after every window of
+iterations with ONE all-reduce (RCCL over xGMI when the tensors live on GPUs).
 
-The reference is single-process (Hogwild threads on one shared vector, sgd.rs:413-593); this is
-the MI355X-native scale-out of it:
-  * rank r owns a subset of the paths (longest-first bin packing on step counts) and samples
-    step a only from its own steps; its share of an iteration's term updates is proportional
-    to its share of the steps, so the global sampling distribution stays uniform over steps;
-  * every rank runs its batch on its own replica of the positions, then the replicas are merged
-    with ONE all-reduce of [delta, touched] in f32 (delta_r = x_r - x_prev, touched_r = delta_r != 0):
-        x <- x_prev + sum_r delta_r / max(1, sum_r touched_r)            (merge="touch", default)
-    A node moved by one rank only receives that rank's full move; a node moved by c ranks
-    receives the mean of the c proposals.  Plain summation (merge="sum") applies c full
-    corrections of the same error and diverges for c >= 3 while the learning rate is still
-    clamped at mu = 1 (measured: stress 1e8 on DRB1 at 4 ranks); plain averaging over all
-    ranks (merge="mean") is stable but under-applies moves of nodes that few ranks touched.
-  * one process per GPU; torch.distributed supplies the collective (backend "nccl" = RCCL).
+The reference is single-process (Hogwild threads on one shared vector, sgd.rs:413-593); this is the MI355X-native
+scale-out of it.  The logic lives BELOW the C ABI (gfasort_amd/csrc/multi.hip, include/gfasort_hip.h
+"multi-device runs"): gfs_shard_paths / gfs_shard_quotas / gfs_shared_node_layout / gfs_exchange_plan plan the run on
+the host, gfs_rank is one rank on one device.  This module is the binding that supplies the collective:
+
+  * `RankDriver`  — the product path: a gfs_rank plus torch.distributed (backend "nccl" = RCCL).  The exchange buffer is
+                    a torch tensor bound into the rank, so the all-reduce runs on it in place.
+  * `ShardedSGD`  — the same plan and the same merge written with torch ops, around an engine that keeps its positions
+                    in a torch tensor in ABI order.  Tests inject a CPU engine built on the oracle to exercise
+                    sharding, quotas, stream bases, idle ranks and the merge under gloo; it is not a product path.
+
+How a window is merged (both classes):
+  * rank r owns a subset of the paths and samples step a only from them; its share of an iteration's term updates is
+    proportional to its share of the steps of multi-step paths, so the global sampling distribution stays uniform;
+  * only the slots that two or more ranks' paths can move are exchanged (all ranks share one node layout; a rank's
+    paths touch one span of it): buf = [delta, touched], delta_r = x_r - x_prev, touched_r = delta_r != 0, and
+        x <- x_prev + sum_r delta_r / max(1, sum_r touched_r)                            (merge="touch", default)
+    A node moved by one rank only receives that rank's full move; a node moved by c ranks receives the mean of the c
+    proposals.  Plain summation (merge="sum") applies c full corrections of the same error and diverges for c >= 3
+    while the learning rate is still clamped at mu = 1 (measured: stress 1e8 on DRB1 at 4 ranks); plain averaging over
+    all ranks (merge="mean") is stable but under-applies moves of nodes that few ranks touched;
+  * slots inside one rank's span only never travel until `finish()`: one full-length f64 all-reduce of "what I own";
+  * a rank whose shard has no multi-step path (or whose quota is 0) is idle: it runs no kernel and contributes zero
+    deltas of the same size as everybody else.
 World size 1 takes none of this path: no collective, no extra kernels.
 """
-from dataclasses import replace
-from typing import Callable, List, Optional
+from typing import Callable, List
 
 import numpy as np
 
 from .graph import FlatGraph
 
-
-def shard_paths_contiguous(step_counts: np.ndarray, world: int) -> List[List[int]]:
-    """Consecutive blocks of paths with (nearly) equal step totals: rank r gets the paths whose
-    cumulative-step midpoint falls into the r-th 1/world of the total."""
-    counts = np.asarray(step_counts, dtype=np.float64)
-    total = float(counts.sum())
-    shards: List[List[int]] = [[] for _ in range(world)]
-    if total <= 0:
-        return shards
-    mid = np.cumsum(counts) - counts / 2.0
-    owner = np.minimum((mid * world / total).astype(np.int64), world - 1)
-    for p, r in enumerate(owner.tolist()):
-        shards[r].append(p)
-    return shards
-
-
-def shard_imbalance(step_counts: np.ndarray, shards: List[List[int]]) -> float:
-    loads = [float(sum(int(step_counts[p]) for p in s)) for s in shards]
-    mean = sum(loads) / max(len(loads), 1)
-    return (max(loads) / mean - 1.0) if mean > 0 else 0.0
-
-
-def shard_paths(step_counts: np.ndarray, world: int) -> List[List[int]]:
-    """Longest-processing-time-first bin packing of paths onto ranks (deterministic)."""
-    order = sorted(range(len(step_counts)), key=lambda p: (-int(step_counts[p]), p))
-    loads = [0] * world
-    shards: List[List[int]] = [[] for _ in range(world)]
-    for p in order:
-        r = min(range(world), key=lambda k: (loads[k], k))
-        shards[r].append(p)
-        loads[r] += int(step_counts[p])
-    for s in shards:
-        s.sort()
-    return shards
+SHARDING = {"auto": 0, "contiguous": 1, "lpt": 2}
 
 
 def shard_quotas(total_updates: int, shard_steps: List[int]) -> List[int]:
-    """Split an iteration's term updates proportionally to step counts (largest remainder),
-    summing exactly to total_updates."""
-    S = sum(shard_steps)
-    if S == 0:
-        return [0] * len(shard_steps)
-    base = [total_updates * s // S for s in shard_steps]
-    rem = total_updates - sum(base)
-    frac = sorted(range(len(shard_steps)), key=lambda k: (-(total_updates * shard_steps[k] % S), k))
-    for k in frac[:rem]:
-        base[k] += 1
-    return base
+    """gfs_shard_quotas: an iteration's term updates split proportionally to step counts (largest remainder)."""
+    from . import hip
+    import ctypes as C
+    steps = np.ascontiguousarray(shard_steps, dtype=np.uint64)
+    out = np.zeros(len(shard_steps), dtype=np.uint64)
+    hip.check(hip.lib().gfs_shard_quotas(C.c_uint64(int(total_updates)), hip._ptr(steps), len(shard_steps), hip._ptr(out)))
+    return [int(v) for v in out]
 
 
 def path_order_layout(g: FlatGraph) -> np.ndarray:
-    """perm[k] = rank of dense node k in first-visit path order (unvisited nodes last): the same
-    rule libgfasort_hip applies by default, computed on the WHOLE graph so that every rank of a
-    multi-GPU run stores its position replica in the same order."""
-    n = g.n_nodes
-    valid = g.step_node[g.step_node != 0xFFFFFFFF].astype(np.int64)
-    perm = np.full(n, -1, dtype=np.int64)
-    if valid.size:
-        uniq, first = np.unique(valid, return_index=True)
-        visited = uniq[np.argsort(first, kind="stable")]
-        perm[visited] = np.arange(visited.size)
-        nxt = visited.size
-    else:
-        nxt = 0
-    rest = np.flatnonzero(perm < 0)
-    perm[rest] = nxt + np.arange(rest.size)
-    return perm.astype(np.uint32)
+    """gfs_shared_node_layout: perm[k] = rank of dense node k in first-visit path order (unvisited nodes last) — the
+    rule libgfasort_hip applies by default, here on the WHOLE graph so that every rank stores its replica alike."""
+    from . import hip
+    import ctypes as C
+    v, keep = hip.make_view(g)
+    perm = np.zeros(max(g.n_nodes, 1), dtype=np.uint32)
+    hip.check(hip.lib().gfs_shared_node_layout(C.byref(v), hip._ptr(perm)))
+    return perm[:g.n_nodes]
 
 
 def subgraph(g: FlatGraph, path_ids: List[int]) -> FlatGraph:
-    """The graph restricted to some paths; all nodes are kept (positions are replicated)."""
+    """The graph restricted to some paths; all nodes are kept."""
     first = g.path_first_step.astype(np.int64)
     segs = [np.arange(first[p], first[p + 1]) for p in path_ids]
     idx = np.concatenate(segs) if segs else np.zeros(0, dtype=np.int64)
@@ -109,102 +73,214 @@ def subgraph(g: FlatGraph, path_ids: List[int]) -> FlatGraph:
     )
 
 
-class ShardedSGD:
-    """Driver for one rank.  `engine_factory(local_graph, params, dims, quota, stream_base)`
-    returns an engine with: .positions (a torch tensor on the compute device, float64, the
-    engine's live position buffer), .run_iteration(k), .stats().  The product engine is
-    HipEngine below; tests inject a CPU engine to exercise this logic under gloo."""
+class _Windows:
+    """Iterations -> merge windows: a window ends after every `merge_every` iterations and after the last one."""
 
-    def __init__(self, graph: FlatGraph, params, rank: int, world: int, engine_factory: Callable,
-                 dims: int = 0, streams_per_rank: int = 0, merge: str = "touch", dist=None,
-                 merge_every: int = 1, sharding: str = "auto", force_merge: bool = False):
-        self.rank, self.world, self.merge = rank, world, merge
-        # force_merge: run the merge (kernels + collective) even with one rank — a 1-rank RCCL group is the
-        # only way to exercise the real collective path on a one-GPU machine (tests)
-        self.merging = world > 1 or (force_merge and dist is not None)
-        self.dist = dist
-        self.merge_every = max(1, int(merge_every))
-        counts = graph.path_step_counts()
-        # consecutive blocks keep a rank's paths (and so the nodes it moves) together when the paths
-        # of the input are ordered along the graph; fall back to LPT packing when that is unbalanced
-        contiguous = shard_paths_contiguous(counts, world)
-        if sharding == "contiguous" or (sharding == "auto" and shard_imbalance(counts, contiguous) <= 0.10):
-            self.shards = contiguous
-        else:
-            self.shards = shard_paths(counts, world)
-        steps = [int(sum(int(counts[p]) for p in s)) for s in self.shards]
-        self.quotas = shard_quotas(int(params.min_term_updates), steps)
-        local = graph if world == 1 else subgraph(graph, self.shards[rank])
-        self.local_graph = local
-        self.params = params
-        self.stream_stride = streams_per_rank
-        # one node layout for all ranks (each rank only sees its own paths)
-        local.shared_node_layout = path_order_layout(graph) if world > 1 else None
-        self.engine = engine_factory(local, params, dims, self.quotas[rank], rank, streams_per_rank)
-        self.x_prev = None
-        self._buf = None
-        if self.merging:
-            import torch
-            self._torch = torch
-            self.x_prev = torch.empty_like(self.engine.positions)
+    def __init__(self, iter_max: int, merge_every: int, merging: bool):
+        self.iter_max, self.every, self.merging = int(iter_max), max(1, int(merge_every)), merging
 
-    def set_positions(self, x: np.ndarray):
-        self.engine.set_positions(x)
-        if self.merging:
-            self.x_prev.copy_(self.engine.positions)
+    def due(self, k: int) -> bool:
+        return self.merging and ((k + 1) % self.every == 0 or k == self.iter_max)
 
-    def _merge_due(self, k: int) -> bool:
-        return self.merging and ((k + 1) % self.merge_every == 0 or k == int(self.params.iter_max))
-
-    def run_iteration(self, k: int):
-        self.engine.run_iteration(k)
-        self._merge_if_due(k)
-
-    def run_range(self, ks):
-        """Iterations ks in order; the iterations between two merges go to the engine as one range
-        (one fused persistent launch on the HIP engine)."""
+    def split(self, ks):
         seg = []
         for k in ks:
             seg.append(int(k))
-            if self._merge_due(int(k)):
-                self._run_segment(seg)
-                self._merge_if_due(int(k))
+            if self.due(int(k)):
+                yield seg, True
                 seg = []
         if seg:
-            self._run_segment(seg)
+            yield seg, False
 
-    def _run_segment(self, seg):
-        if hasattr(self.engine, "run_range"):
-            self.engine.run_range(seg)
-        else:
-            for k in seg:
-                self.engine.run_iteration(k)
 
-    def _merge_if_due(self, k: int):
-        if self._merge_due(k):
-            torch = self._torch
-            x = self.engine.positions
-            n = x.shape[0]
-            if self._buf is None:
-                self._buf = torch.empty((2, n), dtype=torch.float32, device=x.device)   # f32 on the wire
-            buf = self._buf
-            divide = {"touch": 0.0, "sum": 1.0, "mean": float(self.world)}[self.merge]
-            if x.is_cuda and hasattr(self.engine, "hip"):
-                # fused HIP kernels on the engine's stream around the one collective
-                st = torch.cuda.current_stream(x.device).cuda_stream
-                self.engine.hip.merge_prepare(x.data_ptr(), self.x_prev.data_ptr(), buf.data_ptr(), n, st)
-                self.dist.all_reduce(buf)                 # RCCL over xGMI
-                self.engine.hip.merge_apply(x.data_ptr(), self.x_prev.data_ptr(), buf.data_ptr(), n, divide, st)
-            else:
-                buf[0] = (x - self.x_prev).to(torch.float32)      # this rank's batch
-                buf[1] = (buf[0] != 0).to(torch.float32)
-                self.dist.all_reduce(buf)
-                div = buf[1].clamp(min=1.0).to(x.dtype) if divide == 0.0 else divide
-                self.x_prev += buf[0].to(x.dtype) / div
-                x.copy_(self.x_prev)
+class RankDriver:
+    """One rank of the product: gfs_rank on one MI355X, the collective from torch.distributed.
+
+    world_for_plan lets a test on a one-GPU box plan for more ranks than the process group has (a one-rank "nccl"
+    group is the only way to run RCCL there): the kernels and the collective run, the peers' moves are simply absent."""
+
+    def __init__(self, graph: FlatGraph, params, rank: int, world: int, dims: int = 0, device_index: int = 0,
+                 streams_per_rank: int = 0, flags: int = 0, block_size: int = 0, merge: str = "touch", dist=None,
+                 merge_every: int = 1, sharding: str = "auto", whole_vector: bool = False, payload_f64: bool = False,
+                 profile: bool = False):
+        import torch
+        from . import hip
+        self._torch, self.hip = torch, hip
+        self.rank, self.world, self.dist = rank, world, dist
+        self.params, self.dims = params, dims
+        self.device = torch.device("cuda", device_index)
+        launch = hip.make_config(n_streams=streams_per_rank, flags=flags, block_size=block_size)
+        self.r = hip.Rank(graph, params, dims, rank, world, device=device_index, sharding=SHARDING[sharding],
+                          merge_every=merge_every, merge_rule=merge, payload_f64=payload_f64, whole_vector=whole_vector,
+                          launch=launch)
+        self.info = self.r.info()
+        self.windows = _Windows(params.iter_max, merge_every, world > 1)
+        self.buf = None
+        if world > 1 and self.info.exchange_count:
+            self.buf = torch.zeros(int(self.info.exchange_count), dtype=torch.float64 if payload_f64 else torch.float32,
+                                   device=self.device)
+            self.r.bind_exchange_buffer(self.buf.data_ptr())
+        self.full = None
+        self.profile = profile
+        self.timing = {"compute_ms": 0.0, "exchange_ms": 0.0, "windows": 0, "exchange_bytes_per_window":
+                       int(self.info.exchange_count) * (8 if payload_f64 else 4)}
+        self._events = []
+
+    def _stream(self):
+        return self._torch.cuda.current_stream(self.device).cuda_stream
+
+    def set_positions(self, x=None):
+        self.r.set_positions(x)
+
+    def reset_streams(self):
+        self.r.reset_streams()
+
+    def _ev(self):
+        e = self._torch.cuda.Event(enable_timing=True)
+        e.record(self._torch.cuda.current_stream(self.device))
+        return e
+
+    def run_range(self, ks):
+        st = self._stream()
+        for seg, merge in self.windows.split(ks):
+            e0 = self._ev() if self.profile else None
+            self.r.window_begin(seg, st)
+            if merge:
+                e1 = self._ev() if self.profile else None
+                if self.buf is not None:
+                    self.dist.all_reduce(self.buf)                  # RCCL over xGMI, on torch's current stream
+                self.r.window_end(st)
+                if self.profile:
+                    self._events.append((e0, e1, self._ev()))
+            elif self.profile:
+                self._events.append((e0, self._ev(), None))
+
+    def run_iteration(self, k):
+        self.run_range([k])
 
     def run(self):
         self.run_range(range(int(self.params.iter_max) + 1))
+        self.finish()
+
+    def finish(self):
+        """Complete the replica: slots only one rank moves are current on that rank alone until now."""
+        if self.world < 2:
+            return
+        torch = self._torch
+        if self.full is None:
+            self.full = torch.zeros(int(self.info.positions_len), dtype=torch.float64, device=self.device)
+        st = self._stream()
+        self.r.finish_begin(self.full.data_ptr(), st)
+        self.dist.all_reduce(self.full)
+        self.r.finish_end(self.full.data_ptr(), st)
+
+    def collect_timing(self):
+        """Sum the recorded events (synchronises): compute (kernels of the windows + prepare) vs exchange (all-reduce + apply)."""
+        self._torch.cuda.synchronize(self.device)
+        for e0, e1, e2 in self._events:
+            self.timing["compute_ms"] += e0.elapsed_time(e1)
+            if e2 is not None:
+                self.timing["exchange_ms"] += e1.elapsed_time(e2)
+                self.timing["windows"] += 1
+        self._events = []
+        return dict(self.timing)
+
+    def positions_numpy(self) -> np.ndarray:
+        return self.r.get_positions()
+
+    def stats(self):
+        return self.r.ctx_stats()
+
+    def close(self):
+        self.r.close()
+
+
+class ShardedSGD:
+    """The same run around a caller-supplied engine (tests: a CPU engine on the oracle, gloo).
+    `engine_factory(local_graph, params, dims, quota, rank, streams_per_rank)` returns an engine with
+    .positions (torch tensor, float64, ABI order: x[dense node] or Layout.coords), .set_positions(x),
+    .run_iteration(k) and .stats()."""
+
+    def __init__(self, graph: FlatGraph, params, rank: int, world: int, engine_factory: Callable,
+                 dims: int = 0, streams_per_rank: int = 0, merge: str = "touch", dist=None,
+                 merge_every: int = 1, sharding: str = "auto", whole_vector: bool = False, payload_f64: bool = False):
+        from . import hip
+        self.rank, self.world, self.merge, self.dist = rank, world, merge, dist
+        self.params, self.dims = params, dims
+        self.plan = hip.ShardPlan(graph, int(params.min_term_updates), world, SHARDING[sharding], whole_vector)
+        self.shards = [self.plan.paths_of(r) for r in range(world)]
+        self.quotas = [int(q) for q in self.plan.quotas]
+        local = graph if world == 1 else subgraph(graph, self.shards[rank])
+        self.local_graph = local
+        local.shared_node_layout = self.plan.perm if world > 1 else None
+        self.idle = world > 1 and self.quotas[rank] == 0
+        self.engine = engine_factory(local, params, dims, self.quotas[rank] if world > 1 else int(params.min_term_updates),
+                                     rank, streams_per_rank)
+        self.windows = _Windows(params.iter_max, merge_every, world > 1)
+        self.payload_f64 = payload_f64
+        self.x_prev = None
+        if world > 1:
+            import torch
+            self._torch = torch
+            n = graph.n_nodes
+            width = 2 * dims if dims else 1
+            slot_shared = np.zeros(n + 1, dtype=np.int64)
+            for lo, hi in self.plan.shared:
+                slot_shared[lo] += 1
+                slot_shared[hi] -= 1
+            in_shared = np.cumsum(slot_shared[:-1]) > 0
+            nodes = np.flatnonzero(in_shared[self.plan.perm.astype(np.int64)])
+            self.idx = torch.from_numpy((nodes[:, None] * width + np.arange(width)[None, :]).reshape(-1).astype(np.int64))
+            owner = np.full(n, -1, dtype=np.int64)
+            for lo, hi, r in self.plan.owned:
+                owner[lo:hi] = r
+            mine = owner[self.plan.perm.astype(np.int64)] == rank
+            self.mine = torch.from_numpy(np.repeat(mine, width))
+            self.x_prev = self.engine.positions[self.idx].clone()
+
+    def set_positions(self, x: np.ndarray):
+        self.engine.set_positions(x)
+        if self.world > 1:
+            self.x_prev = self.engine.positions[self.idx].clone()
+
+    def run_iteration(self, k: int):
+        self.run_range([k])
+
+    def run_range(self, ks):
+        for seg, merge in self.windows.split(ks):
+            if not self.idle:
+                for k in seg:
+                    self.engine.run_iteration(k)
+            if merge:
+                self._merge()
+
+    def _merge(self):
+        torch = self._torch
+        x = self.engine.positions
+        dt = torch.float64 if self.payload_f64 else torch.float32
+        d = x[self.idx] - self.x_prev                                # this rank's moves of the shared slots
+        buf = torch.stack([d.to(dt), (d != 0).to(dt)])
+        self.dist.all_reduce(buf)
+        if self.merge == "touch":
+            div = buf[1].clamp(min=1.0).to(x.dtype)
+        else:
+            div = 1.0 if self.merge == "sum" else float(self.world)
+        self.x_prev = self.x_prev + buf[0].to(x.dtype) / div
+        x[self.idx] = self.x_prev
+
+    def finish(self):
+        if self.world < 2:
+            return
+        torch = self._torch
+        x = self.engine.positions
+        full = torch.where(self.mine, x, torch.zeros_like(x))
+        self.dist.all_reduce(full)
+        x.copy_(full)
+        self.x_prev = x[self.idx].clone()
+
+    def run(self):
+        self.run_range(range(int(self.params.iter_max) + 1))
+        self.finish()
 
     def positions_numpy(self) -> np.ndarray:
         """Positions in the ABI's dense-index order."""
@@ -214,8 +290,8 @@ class ShardedSGD:
 
 
 class HipEngine:
-    """The product engine: gfs_ctx on one MI355X, positions in a torch CUDA tensor bound into
-    the context so torch.distributed can all-reduce them in place."""
+    """One gfs_ctx on one MI355X behind the engine interface (single-GPU legs of bench.py; a test engine for
+    ShardedSGD is NOT what this is for: N > 1 on GPUs goes through RankDriver)."""
 
     def __init__(self, local_graph, params, dims, quota, rank, streams_per_rank, device_index=0,
                  flags=0, block_size=0):
@@ -232,15 +308,9 @@ class HipEngine:
         self.cfg = cfg
         rc = self.ctx.setup_nd(params, cfg) if dims else self.ctx.setup_1d(params, cfg)
         self.nothing_to_do = rc == hip.NOTHING_TO_DO
-        n = self.ctx.positions_len()
-        self.positions = torch.zeros(max(n, 1), dtype=torch.float64, device=self.device)[:n]
-        if n:
-            self.ctx.bind_positions(self.positions.data_ptr())
 
     def set_positions(self, x):
-        # through the ABI: it applies the context's internal node layout
         self.ctx.upload(np.ascontiguousarray(x, dtype=np.float64))
-        self._torch.cuda.synchronize(self.device)
 
     def get_positions(self):
         return self.ctx.download()
@@ -261,10 +331,3 @@ class HipEngine:
 
     def close(self):
         self.ctx.close()
-
-
-def hip_engine_factory(device_index=0, flags=0, block_size=0):
-    def make(local_graph, params, dims, quota, rank, streams_per_rank):
-        return HipEngine(local_graph, params, dims, quota, rank, streams_per_rank,
-                         device_index=device_index, flags=flags, block_size=block_size)
-    return make

@@ -14,12 +14,12 @@ OK, NOTHING_TO_DO = 0, 1
 F_PLAIN_LOADS, F_NO_LDS_TABLES, F_NO_FUSE = 1, 2, 4
 
 
-F_DBG_NO_ATOMICS, F_DBG_NO_XLOADS, F_DBG_NO_DEFER, F_DBG_ONE_COLOUR = 0x100, 0x200, 0x400, 0x800
-F_DBG_NO_ALIGN, F_DBG_ALIGN_FIRST, F_DBG_WIDE_INDEX = 0x1000, 0x2000, 0x4000
+F_DBG_NO_ATOMICS, F_DBG_NO_XLOADS, F_DBG_ONE_COLOUR = 0x100, 0x200, 0x800
+F_DBG_NO_ALIGN, F_DBG_ALIGN_FIRST, F_DBG_WIDE_INDEX, F_DBG_NO_FUSED_TRIP = 0x1000, 0x2000, 0x4000, 0x8000
 
 
 def F_CHAIN(k):
-    """GFS_F_CHAIN(k): longest run in trips at B = 64 (0 = auto = 16, else a power of two <= 64)."""
+    """GFS_F_CHAIN(k): longest run in trips at B = 64 (0 = auto = 64, else a power of two <= 64)."""
     return (int(k) & 0xFF) << 24
 
 
@@ -65,6 +65,21 @@ class Stats(C.Structure):
                 ("total_ms", C.c_double), ("launches", C.c_uint64), ("run_trips", C.c_uint64)]
 
 
+class RankConfig(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("device", C.c_int32), ("sharding", C.c_uint32),
+                ("merge_every", C.c_uint32), ("merge_rule", C.c_uint32), ("payload", C.c_uint32), ("exchange", C.c_uint32),
+                ("launch", LaunchConfig)]
+
+
+class RankInfo(C.Structure):
+    _fields_ = [("quota", C.c_uint64), ("shard_steps", C.c_uint64), ("span_lo", C.c_uint64), ("span_hi", C.c_uint64),
+                ("shared_slots", C.c_uint64), ("exchange_count", C.c_uint64), ("positions_len", C.c_uint64),
+                ("windows", C.c_uint64), ("last_merge_kernels_ms", C.c_double), ("idle", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
+MERGE_RULES = {"touch": 0, "sum": 1, "mean": 2}
+
 TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)
 
 # every symbol include/gfasort_hip.h declares
@@ -77,6 +92,11 @@ EXPORTS = [
     "gfs_ctx_upload_positions", "gfs_ctx_download_positions", "gfs_ctx_positions_device",
     "gfs_ctx_bind_positions", "gfs_ctx_reset_streams", "gfs_ctx_run_iteration", "gfs_ctx_run_range", "gfs_ctx_run",
     "gfs_ctx_synchronize", "gfs_ctx_stats", "gfs_ctx_sort_order", "gfs_ctx_trace", "gfs_merge_prepare", "gfs_merge_apply",
+    "gfs_shard_paths", "gfs_shard_quotas", "gfs_shared_node_layout", "gfs_exchange_plan",
+    "gfs_rank_create", "gfs_rank_destroy", "gfs_rank_ctx", "gfs_rank_get_info", "gfs_rank_set_positions",
+    "gfs_rank_positions_changed", "gfs_rank_get_positions", "gfs_rank_exchange_count", "gfs_rank_exchange_buffer",
+    "gfs_rank_bind_exchange_buffer", "gfs_rank_window_begin", "gfs_rank_window_end", "gfs_rank_finish_begin",
+    "gfs_rank_finish_buffer", "gfs_rank_finish_end", "gfs_rank_run",
 ]
 
 _lib = None
@@ -124,6 +144,31 @@ def lib():
         L.gfs_sort_order.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.gfs_merge_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.gfs_merge_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
+        L.gfs_shard_paths.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.gfs_shard_quotas.argtypes = [C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.gfs_shared_node_layout.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_exchange_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
+        L.gfs_rank_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.gfs_rank_destroy.argtypes = [C.c_void_p]
+        L.gfs_rank_destroy.restype = None
+        L.gfs_rank_ctx.argtypes = [C.c_void_p]
+        L.gfs_rank_ctx.restype = C.c_void_p
+        L.gfs_rank_get_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_rank_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.gfs_rank_positions_changed.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_rank_get_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.gfs_rank_exchange_count.argtypes = [C.c_void_p]
+        L.gfs_rank_exchange_count.restype = C.c_uint64
+        L.gfs_rank_exchange_buffer.argtypes = [C.c_void_p]
+        L.gfs_rank_exchange_buffer.restype = C.c_void_p
+        L.gfs_rank_bind_exchange_buffer.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_rank_window_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.gfs_rank_window_end.argtypes = [C.c_void_p, C.c_void_p]
+        L.gfs_rank_finish_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gfs_rank_finish_buffer.argtypes = [C.c_void_p]
+        L.gfs_rank_finish_buffer.restype = C.c_void_p
+        L.gfs_rank_finish_end.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gfs_rank_run.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -220,6 +265,124 @@ def merge_prepare(x_ptr, x_prev_ptr, buf_ptr, n, stream=None):
 def merge_apply(x_ptr, x_prev_ptr, buf_ptr, n, divide_all_by=0.0, stream=None):
     check(lib().gfs_merge_apply(C.c_void_p(x_ptr), C.c_void_p(x_prev_ptr), C.c_void_p(buf_ptr), C.c_uint64(n),
                                 C.c_double(divide_all_by), C.c_void_p(stream or 0)))
+
+
+# ---- multi-device planning (host only) and the rank object -------------------------------------
+class ShardPlan:
+    """gfs_shard_paths / gfs_shard_quotas / gfs_shared_node_layout / gfs_exchange_plan of a graph for `world` ranks."""
+
+    def __init__(self, g, min_term_updates, world, sharding=0, whole_vector=False):
+        v, keep = make_view(g)
+        self.world = world
+        self.path_owner = np.zeros(max(g.n_paths, 1), dtype=np.uint32)
+        self.rank_steps = np.zeros(world, dtype=np.uint64)
+        check(lib().gfs_shard_paths(C.byref(v), world, sharding, _ptr(self.path_owner), _ptr(self.rank_steps)))
+        self.path_owner = self.path_owner[:g.n_paths]
+        self.quotas = np.zeros(world, dtype=np.uint64)
+        check(lib().gfs_shard_quotas(C.c_uint64(int(min_term_updates)), _ptr(self.rank_steps), world, _ptr(self.quotas)))
+        self.perm = np.zeros(max(g.n_nodes, 1), dtype=np.uint32)
+        check(lib().gfs_shared_node_layout(C.byref(v), _ptr(self.perm)))
+        self.perm = self.perm[:g.n_nodes]
+        self.span_lo, self.span_hi = np.zeros(world, dtype=np.uint64), np.zeros(world, dtype=np.uint64)
+        seg_lo, seg_hi = np.zeros(2 * world, dtype=np.uint64), np.zeros(2 * world, dtype=np.uint64)
+        own_lo, own_hi = np.zeros(2 * world, dtype=np.uint64), np.zeros(2 * world, dtype=np.uint64)
+        own_rank = np.zeros(2 * world, dtype=np.uint32)
+        n_seg, n_own = C.c_uint32(0), C.c_uint32(0)
+        po = np.ascontiguousarray(self.path_owner) if g.n_paths else np.zeros(1, dtype=np.uint32)
+        pm = np.ascontiguousarray(self.perm) if g.n_nodes else np.zeros(1, dtype=np.uint32)
+        check(lib().gfs_exchange_plan(C.byref(v), _ptr(pm), _ptr(po), world, _ptr(self.span_lo), _ptr(self.span_hi),
+                                      _ptr(seg_lo), _ptr(seg_hi), C.byref(n_seg), _ptr(own_lo), _ptr(own_hi), _ptr(own_rank),
+                                      C.byref(n_own)))
+        self.shared = [(int(seg_lo[k]), int(seg_hi[k])) for k in range(n_seg.value)]      # slots two or more ranks can move
+        if whole_vector and g.n_nodes:
+            self.shared = [(0, g.n_nodes)]
+        self.owned = [(int(own_lo[k]), int(own_hi[k]), int(own_rank[k])) for k in range(n_own.value)]
+
+    def paths_of(self, rank):
+        return np.flatnonzero(self.path_owner == rank).tolist()
+
+
+class Rank:
+    """gfs_rank: one rank of a multi-device run (its shard's context, the exchange of the shared slots)."""
+
+    def __init__(self, g, p, dims, rank, world, device=0, sharding=0, merge_every=1, merge_rule="touch", payload_f64=False,
+                 whole_vector=False, launch=None):
+        self.graph, self.params, self.dims = g, p, dims
+        v, self._keep = make_view(g)
+        cfg = RankConfig(rank, world, device, sharding, merge_every, MERGE_RULES[merge_rule], 1 if payload_f64 else 0,
+                         1 if whole_vector else 0, launch if launch is not None else LaunchConfig())
+        self.cfg = cfg
+        sp = make_sgd_params(p)
+        self._h = C.c_void_p()
+        self.rc = check(lib().gfs_rank_create(C.byref(v), C.byref(sp), C.c_uint64(dims), C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().gfs_rank_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        out = RankInfo()
+        check(lib().gfs_rank_get_info(self._h, C.byref(out)))
+        return out
+
+    def ctx_stats(self):
+        st = Stats()
+        check(lib().gfs_ctx_stats(C.c_void_p(lib().gfs_rank_ctx(self._h)), C.byref(st)))
+        return st
+
+    def reset_streams(self):
+        check(lib().gfs_ctx_reset_streams(C.c_void_p(lib().gfs_rank_ctx(self._h))))
+
+    def set_positions(self, x=None):
+        if x is None:
+            check(lib().gfs_rank_set_positions(self._h, None, 0))
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            check(lib().gfs_rank_set_positions(self._h, _ptr(x), x.shape[0]))
+
+    def get_positions(self):
+        x = np.zeros(int(self.info().positions_len), dtype=np.float64)
+        check(lib().gfs_rank_get_positions(self._h, _ptr(x), x.shape[0]))
+        return x
+
+    def exchange_count(self):
+        return int(lib().gfs_rank_exchange_count(self._h))
+
+    def bind_exchange_buffer(self, device_ptr):
+        check(lib().gfs_rank_bind_exchange_buffer(self._h, C.c_void_p(device_ptr)))
+
+    def window_begin(self, ks, stream=None):
+        ks = np.ascontiguousarray(ks, dtype=np.uint64)
+        return check(lib().gfs_rank_window_begin(self._h, _ptr(ks), C.c_uint64(ks.shape[0]), C.c_void_p(stream or 0)))
+
+    def window_end(self, stream=None):
+        check(lib().gfs_rank_window_end(self._h, C.c_void_p(stream or 0)))
+
+    def finish_begin(self, full_device_ptr, stream=None):
+        check(lib().gfs_rank_finish_begin(self._h, C.c_void_p(full_device_ptr), C.c_void_p(stream or 0)))
+
+    def finish_end(self, full_device_ptr, stream=None):
+        check(lib().gfs_rank_finish_end(self._h, C.c_void_p(full_device_ptr), C.c_void_p(stream or 0)))
+
+    def run(self, allreduce=None, stream=None):
+        """gfs_rank_run with a Python collective: allreduce(device_ptr, count, is_f64, stream) -> None."""
+        def tramp(user, buf, count, is_f64, st):
+            try:
+                allreduce(buf, count, bool(is_f64), st)
+                return 0
+            except Exception:                                  # never raise through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLREDUCE_FN(tramp) if allreduce is not None else C.cast(None, ALLREDUCE_FN)
+        return check(lib().gfs_rank_run(self._h, cb, None, C.c_void_p(stream or 0)))
 
 
 # ---- resident context ------------------------------------------------------------------------

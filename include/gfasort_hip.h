@@ -44,8 +44,9 @@ typedef struct gfs_graph_view {
     uint64_t        n_nodes;          /* graph.node_count()                       sgd.rs:241 */
     uint64_t        n_steps;          /* PathIndex::get_total_steps()             sgd.rs:73  */
     uint64_t        n_paths;          /* PathIndex::num_paths()                   sgd.rs:101 */
-                                       /* limits of the device mirror: n_nodes < 2^31, n_paths < 2^22,
-                                          n_steps <= 2^40, < 2^32 steps per path (GFS_E_UNSUPPORTED beyond) */
+                                       /* limits of the device mirror: n_nodes < 2^31, n_paths < 2^31,
+                                          n_steps <= 2^40, < 2^32 steps and < 2^55 bp per path
+                                          (GFS_E_UNSUPPORTED beyond) */
     const uint32_t *node_len;         /* [n_nodes]  sequence.len() by dense index            */
     const uint32_t *step_node;        /* [n_steps]  dense index of the step's node, or
                                          GFS_NO_NODE when the id is absent from the graph
@@ -105,18 +106,18 @@ typedef struct gfs_launch_config {
  * graphs (< 16384 nodes), else up to 64 while an iteration still has >= 4096 independent draws. */
 #define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* n in {0 = auto, 1, 4, 8, 16, 32, 64} */
 /* Long runs: with bundles of 64 a sampled (step a, jump) is expanded over k consecutive trips of its wave, i.e. over
- * 64*k consecutive steps (k adapts downwards on short paths).  k = 0 (default): 16.  k = 1: a run is one trip. */
+ * 64*k consecutive steps (k adapts downwards on short paths).  k = 0 (default): 64.  k = 1: a run is one trip. */
 #define GFS_F_CHAIN(k) (((uint32_t)(k) & 0xFFu) << 24)   /* k in {0 = auto, 1, 2, 4, 8, 16, 32, 64} */
 #define GFS_F_NO_FUSE       4u        /* gfs_ctx_run / gfs_ctx_run_range: one launch per iteration even where
                                          a fused persistent launch is possible                        */
 #define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
 #define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
-#define GFS_F_DBG_NO_DEFER    0x400u  /* test hook: team kernels issue a trip's adds in that trip (one wave is then
-                                         an exact replay of the oracle's sequential mirror)                   */
 #define GFS_F_DBG_ONE_COLOUR   0x800u  /* diagnostic: short-jump runs execute their first colour only (round-1 behaviour:
                                          half of the run's terms, i.e. short jumps under-sampled)                  */
 #define GFS_F_DBG_NO_ALIGN      0x1000u /* diagnostic: bundled sampler without line-aligned runs               */
 #define GFS_F_DBG_ALIGN_FIRST   0x2000u /* diagnostic: line-align only the first run of a bundle               */
+#define GFS_F_DBG_NO_FUSED_TRIP 0x8000u /* diagnostic: the two colours of a short-jump run as two trips even where one
+                                         fused trip is possible (same terms, same order)                        */
 #define GFS_F_DBG_WIDE_INDEX 0x4000u  /* test hook: draw step indices with the u64 sampler that graphs of
                                          more than 2^32-1 steps use (rand's usize sampler switches there) */
 
@@ -218,10 +219,82 @@ int   gfs_ctx_stats(gfs_ctx *ctx, gfs_stats *out);               /* synchronises
 int   gfs_ctx_sort_order(gfs_ctx *ctx, uint64_t *order, uint64_t n_nodes);
 int   gfs_ctx_trace(gfs_ctx *ctx, gfs_term *out, uint64_t n_terms, uint64_t *counts, uint64_t n_streams);
 
-/* ---- multi-GPU replica merge (device pointers; no reference equivalent) ----
- * One iteration on R ranks: every rank runs its batch on its replica x, then
- *   gfs_merge_prepare: buf[0..n) = (float)(x - x_prev), buf[n..2n) = (delta != 0)   (f32: half the bytes)
- *   all-reduce(sum) of buf over the ranks (RCCL; the caller's collective)
+/* ---- multi-device runs (no reference equivalent: the reference is one process, src/sgd.rs:413-593) ----
+ * Paths are sharded over `world` ranks, one rank per GPU (one process per GPU, or one host thread per GPU); every rank
+ * performs its share of an iteration's term updates on its own replica of the positions; after every window of
+ * iterations the replicas are merged.  The collective itself is the CALLER's (RCCL over xGMI: torch.distributed, or
+ * ncclAllReduce from the Rust host): the library hands out the device buffer to sum over the ranks and runs the kernels
+ * on either side of it.  Only the slots that more than one rank's paths can move are exchanged (all ranks store the
+ * positions in one node layout, first-visit path order of the whole graph; a rank's paths touch one span of it);
+ * gfs_rank_finish_* completes every replica at the end with one full-length f64 sum.                                  */
+#define GFS_MAX_WORLD 64
+
+typedef struct gfs_rank gfs_rank;
+
+typedef struct gfs_rank_config {
+    uint32_t rank, world;
+    int32_t  device;                  /* HIP device of this rank                                                  */
+    uint32_t sharding;                /* 0 auto, 1 consecutive blocks of paths, 2 longest-first bin packing       */
+    uint32_t merge_every;             /* iterations per merge window (0 = 1); the last iteration always merges    */
+    uint32_t merge_rule;              /* 0: a slot's summed move / number of ranks that moved it; 1 sum; 2 mean   */
+    uint32_t payload;                 /* exchange buffer element type: 0 f32, 1 f64                               */
+    uint32_t exchange;                /* 0: only the slots two or more ranks can move; 1: the whole vector        */
+    gfs_launch_config launch;         /* per-rank launch shape; term_updates_per_iteration and stream_base are set
+                                         by the library (quota of the rank; rank * n_streams)                     */
+} gfs_rank_config;
+
+typedef struct gfs_rank_info {
+    uint64_t quota;                   /* this rank's term updates per iteration                                   */
+    uint64_t shard_steps;             /* steps of its multi-step paths                                            */
+    uint64_t span_lo, span_hi;        /* slots [lo, hi) its paths touch in the shared node layout                 */
+    uint64_t shared_slots;            /* slots two or more ranks can move (what a window exchanges)               */
+    uint64_t exchange_count;          /* elements of the payload type in the exchange buffer: [delta | touched]   */
+    uint64_t positions_len;           /* n_nodes (1D) or n_nodes*2*D                                              */
+    uint64_t windows;                 /* merge windows completed                                                  */
+    double   last_merge_kernels_ms;   /* prepare + apply kernels of the last window (HIP events)                  */
+    uint32_t idle;                    /* 1: no term updates here (no multi-step path in the shard, or quota 0)    */
+    uint32_t _pad;
+} gfs_rank_info;
+
+/* host-only planning (no device): also what a caller needs to drive gfs_ctx ranks itself */
+int gfs_shard_paths(const gfs_graph_view *g, uint32_t world, uint32_t sharding, uint32_t *path_owner /*[n_paths]*/,
+                    uint64_t *rank_steps /*[world]*/);
+int gfs_shard_quotas(uint64_t term_updates, const uint64_t *rank_steps, uint32_t world, uint64_t *rank_quota /*[world]*/);
+int gfs_shared_node_layout(const gfs_graph_view *g, uint32_t *perm /*[n_nodes]*/);
+int gfs_exchange_plan(const gfs_graph_view *g, const uint32_t *perm, const uint32_t *path_owner, uint32_t world,
+                      uint64_t *span_lo, uint64_t *span_hi /*[world]*/,
+                      uint64_t *seg_lo, uint64_t *seg_hi /*[2*world]*/, uint32_t *n_seg,
+                      uint64_t *own_lo, uint64_t *own_hi, uint32_t *own_rank /*[2*world] or NULL*/, uint32_t *n_own);
+
+/* one rank.  g is the WHOLE graph (every rank derives the same plan from it and keeps only its shard on the device);
+ * dims = 0: path_linear_sgd, else path_linear_sgd_layout with that many dimensions.                                  */
+int      gfs_rank_create(const gfs_graph_view *g, const gfs_sgd_params *p, uint64_t dims, const gfs_rank_config *cfg,
+                         gfs_rank **out);
+void     gfs_rank_destroy(gfs_rank *r);
+gfs_ctx *gfs_rank_ctx(gfs_rank *r);                               /* the rank's context (stats, raw device pointer)  */
+int      gfs_rank_get_info(const gfs_rank *r, gfs_rank_info *out);
+int      gfs_rank_set_positions(gfs_rank *r, const double *host, uint64_t n);  /* ABI order; NULL = the reference's 1D start */
+int      gfs_rank_positions_changed(gfs_rank *r, void *hip_stream);            /* after writing the device buffer directly */
+int      gfs_rank_get_positions(gfs_rank *r, double *host, uint64_t n);        /* complete after gfs_rank_finish_*    */
+uint64_t gfs_rank_exchange_count(const gfs_rank *r);
+void    *gfs_rank_exchange_buffer(gfs_rank *r);                   /* device pointer (allocated on first use)         */
+int      gfs_rank_bind_exchange_buffer(gfs_rank *r, void *device_ptr);         /* use the caller's (a torch tensor)   */
+/* a merge window: [this rank's share of iterations ks[0..n), moves -> buffer] | caller: all-reduce(sum) | [apply]    */
+int      gfs_rank_window_begin(gfs_rank *r, const uint64_t *ks, uint64_t n, void *hip_stream);
+int      gfs_rank_window_end(gfs_rank *r, void *hip_stream);
+/* completion: [owned slots -> full (NULL: library scratch, gfs_rank_finish_buffer)] | all-reduce(sum, f64,
+ * positions_len) | [full -> positions]                                                                               */
+int      gfs_rank_finish_begin(gfs_rank *r, double *full_device, void *hip_stream);
+double  *gfs_rank_finish_buffer(gfs_rank *r);
+int      gfs_rank_finish_end(gfs_rank *r, const double *full_device, void *hip_stream);
+/* the whole schedule.  allreduce must sum device_buf[0..count) over all ranks in place, ordered on hip_stream, and
+ * return 0.  Never called when world == 1.                                                                           */
+typedef int (*gfs_allreduce_fn)(void *user, void *device_buf, uint64_t count, int is_f64, void *hip_stream);
+int      gfs_rank_run(gfs_rank *r, gfs_allreduce_fn allreduce, void *user, void *hip_stream);
+
+/* ---- round-1 whole-vector merge kernels (device pointers), kept for callers that drive gfs_ctx ranks themselves ----
+ *   gfs_merge_prepare: buf[0..n) = (float)(x - x_prev), buf[n..2n) = (delta != 0)
+ *   all-reduce(sum) of buf over the ranks
  *   gfs_merge_apply  : x_prev += sum_delta / max(1, sum_touched)  (divide_all_by = 0), or
  *                      x_prev += sum_delta / divide_all_by         (1 = plain sum, R = mean); x = x_prev */
 int gfs_merge_prepare(const double *x, const double *x_prev, float *buf2n, uint64_t n, void *hip_stream);

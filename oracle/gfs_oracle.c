@@ -527,7 +527,7 @@ struct gfo_state {
     uint64_t T, D, quota_total, attempt_factor, bundle;
     uint64_t *rng, *done, *att, *ntr;
     struct leader_s *lead; uint8_t *lead_left, *lead_cool, *lead_colour, *lead_seg;   /* 1D bundled mode: each wave's partly expanded pass */
-    uint64_t chain;                                           /* longest run in trips (B = 64, 1D); mirror of GFS_F_CHAIN */
+    uint64_t chain;                                           /* longest run in trips (B = 64); mirror of GFS_F_CHAIN */
     int one_colour;                                           /* mirror of GFS_F_DBG_ONE_COLOUR */
     uint32_t *node_slot;                                     /* bundled mode: the product's internal node layout (line-aligned runs) */
     gfo_term *trace; uint64_t trace_per_stream;
@@ -603,18 +603,25 @@ int gfo_state_set_bundle(gfo_state *s, uint64_t bundle) {
 }
 
 /* Long runs (product: sgd_device.h run_trips): with B = 64 in 1D a leader is expanded over K consecutive trips of its
- * wave, K = the largest power of two <= chain with K*B <= cnt/4.  chain = 1: a run is one trip. */
+ * wave, K = the largest power of two <= chain with K*B <= cnt/4.  chain = 1: a run is one trip.  1D and nD alike. */
 int gfo_state_set_chain(gfo_state *s, uint64_t chain) {
     if (!s || chain == 0 || chain > 64 || (chain & (chain - 1))) return -1;
     s->chain = chain;
     return 0;
 }
 static uint64_t run_trips(const gfo_state *s, uint64_t cnt) {
-    if (s->bundle != 64 || s->D != 0) return 1;
+    if (s->bundle != 64) return 1;
     const uint64_t room = cnt / (4 * s->bundle);
     if (room < 2 || s->chain < 2) return 1;
     uint64_t p2 = 1; while (p2 * 2 <= room) p2 *= 2;
     return p2 < s->chain ? p2 : s->chain;
+}
+/* where trip seg of a run starts, in steps after the run's first step: long-jump runs are contiguous, a leader whose
+ * jump is shorter than a trip spreads its trips evenly over the path (product: sgd_device.h run_offset) */
+static uint64_t run_offset(const gfo_state *s, uint64_t cnt, uint64_t k, uint64_t ra0, uint64_t rb0, uint64_t seg) {
+    if (s->bundle != 64) return 0;
+    const uint64_t z = ra0 < rb0 ? rb0 - ra0 : ra0 - rb0;
+    return seg * (z < s->bundle ? cnt / k : s->bundle);
 }
 
 /* mirror of GFS_F_DBG_ONE_COLOUR: short-jump runs execute their first colour only (the round-1 sampler) */
@@ -750,13 +757,13 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                 s->lead_left[w] = (uint8_t)B; s->lead_cool[w] = (uint8_t)it.cooling; s->lead_colour[w] = 0; s->lead_seg[w] = 0;
             }
             /* trips: slot t of the pass, colour 0, then — when some run of the slot has a jump shorter than the run
-             * (1D only; sgd_device.h two_colour) — the same slot with colour 1: the run's terms chain through shared
+             * (sgd_device.h two_colour) — the same slot with colour 1: the run's terms chain through shared
              * nodes, each colour is node-disjoint, together they are every term of the run */
             while (s->lead_left[w] > 0 && wave_done < wave_quota) {
                 const uint64_t t = B - s->lead_left[w];
                 const uint64_t colour = s->lead_colour[w], seg = s->lead_seg[w];
                 int two = 0;
-                for (uint64_t qq = 0; qq < RUNS && carry && !s->one_colour; qq++) {
+                for (uint64_t qq = 0; qq < RUNS && !s->one_colour; qq++) {
                     const leader_t *ld = &L[t * RUNS + qq];
                     const int64_t shift = (int64_t)ld->rb0 - (int64_t)ld->ra0;
                     if (ld->ok && !ld->aligned && ld->cnt >= 2 * B && shift < (int64_t)B && shift > -(int64_t)B) two = 1;
@@ -773,20 +780,22 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                     const leader_t *ld = &L[t * RUNS + qq];
                     const int64_t shift = (int64_t)ld->rb0 - (int64_t)ld->ra0;
                     const uint64_t zabs = (uint64_t)(shift < 0 ? -shift : shift);
+                    const uint64_t off = run_offset(s, ld->cnt, ktrips, ld->ra0, ld->rb0, seg);
                     for (uint64_t sub = 0; sub < B; sub++) {
                         const uint64_t l = qq * B + sub;
-                        const uint64_t pl = seg * B + sub;              /* place in the run */
+                        const uint64_t pl = off + sub;                  /* place in the run */
                         valid[l] = 0;
                         if (!ld->ok) continue;
                         uint64_t ra = ld->ra0, rb = ld->rb0;
                         if (ld->aligned) {                              /* both runs are aligned blocks inside the path */
                             if (colour) continue;
-                            ra = ld->ra0 + pl; rb = ld->rb0 + seg * B + ((sub + (uint64_t)ld->rot) % B);
+                            ra = ld->ra0 + pl; rb = ld->rb0 + off + ((sub + (uint64_t)ld->rot) % B);
                         } else if (pl != 0 || colour) {
                             if (ld->cnt < 2 * B) continue;
                             if (zabs < B) { if (((pl / zabs) & 1) != colour) continue; }
                             else if (colour) continue;
                             ra = ld->ra0 + pl;
+                            if (ra >= ld->cnt) ra -= ld->cnt;
                             if (ra >= ld->cnt) ra -= ld->cnt;
                             int64_t tt = (int64_t)ra + shift;
                             if (tt < 0 || tt > (int64_t)ld->cnt - 1) {          /* mirror the jump (|jump| >= B only) */

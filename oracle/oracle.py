@@ -236,7 +236,7 @@ class State:
         if one_colour:
             assert lib().gfo_state_set_one_colour(self.h, C.c_int(1)) == 0
         if chain != 1:
-            # the product's long runs (GFS_F_CHAIN; its default at B = 64 is 16)
+            # the product's long runs (GFS_F_CHAIN; its default at B = 64 is 64)
             assert lib().gfo_state_set_chain(self.h, C.c_uint64(chain)) == 0
         if node_slots is not None:
             # the product's internal node layout (hip.Context.node_layout()): its bundled sampler aligns runs to it

@@ -1,8 +1,18 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle.
 
-P0  replay: ONE stream on the GPU == oracle single stream, bit for bit (positions).
-P0' sampler: the first k terms (i, j, d_ij) of EVERY stream at full width == oracle, bit for bit
-    (sampling does not depend on positions, so this is exact at any width).
+PARITY with the reference's algorithm (the oracle restates src/sgd.rs line by line):
+  P0  replay: ONE stream on the GPU == oracle single stream, bit for bit (positions, coordinates).
+  P0' sampler: the first k terms (i, j, d_ij) of EVERY reference stream at full width == oracle, bit for bit
+      (sampling does not depend on positions, so this is exact at any width).
+  P1  graphs with a unique optimum sort in exact chain order; P2 quality at equal update counts (tests/test_gpu_quality.py
+      holds the large-graph P2 tests of the default flags).
+
+IMPLEMENTATION = SPECIFICATION for the team kernels (bundled sampling, long runs, two colours): they are NOT the
+reference's sampler — the reference samples every term independently (sgd.rs:444-497) — and `oracle/gfs_oracle.c`
+holds a mirror of them that the builder wrote ("NOT in the reference").  The tests named *_oracle_mirror compare the
+kernels with that mirror bit for bit: they prove that the kernel does what its specification says (random-number
+consumption, emitted terms, arithmetic, quotas, carry-over), nothing about the reference.  What ties the team kernels to
+the reference is P1 and P2 only.
 """
 import numpy as np
 import pytest
@@ -265,15 +275,16 @@ def _node_slots(g):
 
 
 def _mirror_chain(B):
-    """The product's default run length in trips (GFS_F_CHAIN auto): 16 at B = 64 in 1D, else one trip per run."""
-    return 16 if B == 64 else 1
+    """The product's default run length in trips (GFS_F_CHAIN auto): 64 at B = 64 (1D and layout), else one trip per run."""
+    return 64 if B == 64 else 1
 
 
 
 @pytest.mark.parametrize("B", [4, 8, 16, 32, 64])
 def test_bundled_sampler_trace_matches_oracle_mirror(B):
-    """The bundled sampler's random-number consumption and emitted terms equal the oracle's mirror of
-    it bit for bit (leader = reference stream, satellites = consecutive steps, wave-level quota)."""
+    """Implementation = specification: the bundled sampler's random-number consumption and emitted terms equal the
+    oracle's MIRROR of it bit for bit (leader = reference stream, satellites = consecutive steps, long runs, two colours,
+    wave-level quota).  Not a statement about the reference."""
     g = load("DRB1-3123.gfa")
     p = _ygs(g, 6)
     T, K = 512, 48
@@ -358,7 +369,7 @@ def test_bundled_nd_sampler_trace_matches_oracle_mirror(B, dims):
     og, op = oracle_graph(g), oracle_params(p)
     c0 = gaussian_init(g, dims, 11)
     c_ref = c0.copy()
-    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g))
+    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g), chain=_mirror_chain(B))
     st_o.run(c_ref)
     so = st_o.stats()
     ctx = hip.Context(g)
@@ -432,21 +443,21 @@ def _mp_rank(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from gfasort_amd.distributed import ShardedSGD, hip_engine_factory
+    from gfasort_amd.distributed import RankDriver
     g = G.synth_bubbles(20000, 16, 5)
     p = _ygs(g, 100)
-    r = ShardedSGD(g, p, rank, world, hip_engine_factory(device_index=0), dims=0, dist=dist)
+    r = RankDriver(g, p, rank, world, dims=0, device_index=0, dist=dist)
     r.set_positions(hip.init_positions(g))
     r.run()
     torch.cuda.synchronize()
     x = r.positions_numpy()
-    st = r.engine.stats()
+    st = r.stats()
     xs = [torch.zeros(x.shape[0], dtype=torch.float64) for _ in range(world)]
     dist.all_gather(xs, torch.from_numpy(x))
     upd = torch.tensor([float(st.term_updates)], dtype=torch.float64)
     dist.all_reduce(upd)
     if rank == 0:
-        out.put((x, [t.numpy() for t in xs], float(upd.item()), r.quotas, int(st.bundle), int(st.n_streams)))
+        out.put((x, [t.numpy() for t in xs], float(upd.item()), int(r.info.quota), int(st.bundle), int(st.n_streams)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -460,14 +471,14 @@ def test_two_ranks_on_one_gpu_hip_engine():
     procs = [ctx.Process(target=_mp_rank, args=(r, 2, port, out)) for r in range(2)]
     for pr in procs:
         pr.start()
-    x, xs, upd, quotas, bundle, streams = out.get(timeout=300)
+    x, xs, upd, quota0, bundle, streams = out.get(timeout=300)
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
     g = G.synth_bubbles(20000, 16, 5)
     p = _ygs(g, 100)
     assert np.array_equal(xs[0], xs[1])                                   # replicas agree after the merge
-    assert sum(quotas) == p.min_term_updates and upd == 101 * p.min_term_updates
+    assert 0 < quota0 < p.min_term_updates and upd == 101 * p.min_term_updates
     og = oracle_graph(g)
     s0 = O.stress_1d(og, O.init_positions(og), 100000)
     rc, x1, st1 = hip.path_linear_sgd_raw(g, p)
@@ -704,15 +715,18 @@ def _rccl_rank(port, out):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    from gfasort_amd.distributed import ShardedSGD, hip_engine_factory
+    from gfasort_amd.distributed import RankDriver
     g = G.synth_windows(1_000_000, 64, 156_250, 2)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
     p.iter_max = 60
-    r = ShardedSGD(g, p, 0, 1, hip_engine_factory(device_index=0), dims=0, dist=dist, merge_every=4, force_merge=True)
+    # planned for two ranks, run as rank 0 of a ONE-rank RCCL group (the only way to have RCCL on a one-GPU box): the
+    # kernels either side of the collective, the exchange buffer as a torch tensor and the collective itself all run;
+    # rank 1's half of the paths is simply never optimised
+    r = RankDriver(g, p, 0, 2, dims=0, device_index=0, dist=dist, merge_every=4)
     r.set_positions(hip.init_positions(g))
     r.run()
     torch.cuda.synchronize()
-    st = r.engine.stats()
+    st = r.stats()
     t = torch.ones(8, device="cuda")
     dist.all_reduce(t)
     out.put((r.positions_numpy(), int(st.term_updates), int(st.launches), float(t.sum().item())))
@@ -734,10 +748,16 @@ def test_one_rank_rccl_group_runs_the_merge_path():
     g = G.synth_windows(1_000_000, 64, 156_250, 2)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
     p.iter_max = 60
-    assert upd == (p.iter_max + 1) * p.min_term_updates
+    assert upd == (p.iter_max + 1) * (p.min_term_updates // 2)          # rank 0's half of every iteration
     assert launches == -(-(p.iter_max + 1) // 4)            # one fused launch per merge window of 4 iterations
-    # merging with nobody is x_prev + f32(x - x_prev): the sort still comes out in exact chain order
-    assert np.isfinite(x).all() and _chain_order_ok(g, x)
+    # rank 0 owns paths 0..31: the nodes they cover come out in exact chain order (merging with nobody is
+    # x_prev + f32(x - x_prev) on the shared slots); the rest of the chain was rank 1's and keeps its start
+    hi = int(g.step_node[: int(g.path_first_step[32])].max())
+    ids = g.node_ids.astype(np.int64)
+    mine = np.flatnonzero(ids <= int(ids[g.step_node[: int(g.path_first_step[32])]].max()))
+    order = mine[np.argsort(x[mine], kind="stable")]
+    d = np.diff(ids[order])
+    assert np.isfinite(x).all() and (np.all(d == 1) or np.all(d == -1)), hi
 
 
 def test_device_node_layout_with_unvisited_nodes_absent_steps_and_bad_indices():
@@ -824,16 +844,16 @@ def _mp_rank_nd(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from gfasort_amd.distributed import ShardedSGD, hip_engine_factory
+    from gfasort_amd.distributed import RankDriver
     from gfasort_amd import sgd as S
     g = G.synth_bubbles(20000, 16, 5)
     p = P.LayoutSGDParams.from_graph(g, 2, 1)
-    r = ShardedSGD(g, p, rank, world, hip_engine_factory(device_index=0), dims=2, dist=dist, merge_every=2)
+    r = RankDriver(g, p, rank, world, dims=2, device_index=0, dist=dist, merge_every=2)
     r.set_positions(S.default_layout_init(g, 2, p.seed).ravel())
     r.run()
     torch.cuda.synchronize()
     c = r.positions_numpy()
-    st = r.engine.stats()
+    st = r.stats()
     cs = [torch.zeros(c.shape[0], dtype=torch.float64) for _ in range(world)]
     dist.all_gather(cs, torch.from_numpy(c))
     upd = torch.tensor([float(st.term_updates)], dtype=torch.float64)
@@ -870,14 +890,14 @@ def test_two_ranks_on_one_gpu_layout_2d():
     assert np.isfinite(c).all() and s1 < 0.1 * s0 and s2 < 0.1 * s0 and s2 < 2.0 * s1 + 1e-3, (s0, s1, s2)
 
 
-# ---- P0 for the team kernel: one wave replays the oracle's sequential mirror bit for bit ----------------------------
+# ---- implementation = specification for the team kernel: one wave replays the oracle's sequential MIRROR bit for bit ----
 @pytest.mark.parametrize("fused", [False, True])
 def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(fused):
-    """One wave of 64 streams, B = 64, atomics issued in the trip that computes them (GFS_F_DBG_NO_DEFER): trips run
+    """Implementation = specification.  One wave of 64 streams, B = 64: trips run
     one after another and the adds of a trip go to distinct nodes on a graph whose paths visit no node twice, so
     the concurrent GPU trip equals the mirror's lane-by-lane application — positions must agree to the last bit.
-    Covers the arithmetic of the product's main kernel including line-aligned runs and merged short-jump trips."""
-    NO_DEFER = 0x400
+    Covers the arithmetic of the product's main kernel including line-aligned long runs, fused two-colour trips and merged
+    short-jump trips at path ends."""
     g = G.synth_windows(40_000, 8, 20_000, 12)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
     p.iter_max = 8
@@ -887,7 +907,7 @@ def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(fused):
     x_ref = O.init_positions(og)
     st_o.run(x_ref)
     so = st_o.stats()
-    flags = hip.F_BUNDLE(64) | NO_DEFER | (0 if fused else hip.F_NO_FUSE)
+    flags = hip.F_BUNDLE(64) | (0 if fused else hip.F_NO_FUSE)
     ctx = hip.Context(g)
     ctx.setup_1d(p, hip.make_config(n_streams=64, flags=flags))
     ctx.upload(hip.init_positions(g))
@@ -911,7 +931,7 @@ def test_layout_team_kernel_single_wave_coords_equal_the_oracle_mirror(dims):
     og, op = oracle_graph(g), oracle_params(p)
     c0 = gaussian_init(g, dims, 5)
     c_ref = c0.copy()
-    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g))
+    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64))
     st_o.run(c_ref)
     so = st_o.stats()
     ctx = hip.Context(g)

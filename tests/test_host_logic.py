@@ -139,13 +139,63 @@ def test_splitmix_array_matches_oracle():
 
 
 # ---- multi-GPU sharding helpers ----------------------------------------------------------------------------
+def _graph_with_counts(counts, n_nodes=64):
+    """A FlatGraph whose paths have the given step counts (steps walk the nodes cyclically)."""
+    steps = np.concatenate([np.arange(c) % n_nodes for c in counts]).astype(np.uint32) if len(counts) else np.zeros(0, np.uint32)
+    return G.FlatGraph(node_len=np.ones(n_nodes, dtype=np.uint32), step_node=steps, step_is_rev=np.zeros(steps.shape[0], np.uint8),
+                       path_first_step=np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64),
+                       node_ids=np.arange(1, n_nodes + 1, dtype=np.uint64), path_names=[f"p{k}" for k in range(len(counts))])
+
+
 def test_shard_paths_balanced_and_complete():
-    counts = np.array([100, 90, 80, 10, 10, 10, 5, 5])
-    shards = D.shard_paths(counts, 3)
-    assert sorted(p for s in shards for p in s) == list(range(8))
-    loads = [int(counts[s].sum()) for s in shards]
-    assert max(loads) - min(loads) <= 20
-    assert D.shard_paths(counts, 1) == [list(range(8))]
+    """gfs_shard_paths (host-only part of the multi-device ABI): every path has one owner, loads are balanced,
+    one-step paths weigh nothing, and blocks are kept when they are balanced."""
+    from gfasort_amd import hip
+    counts = [100, 90, 80, 10, 10, 10, 5, 5, 1, 1]
+    g = _graph_with_counts(counts)
+    plan = hip.ShardPlan(g, 1000, 3)
+    assert sorted(p for r in range(3) for p in plan.paths_of(r)) == list(range(10))
+    loads = [sum(counts[p] for p in plan.paths_of(r) if counts[p] > 1) for r in range(3)]
+    assert loads == [int(v) for v in plan.rank_steps] and max(loads) - min(loads) <= 20      # unbalanced blocks -> bin packing
+    assert int(plan.quotas.sum()) == 1000
+    assert hip.ShardPlan(g, 1000, 1).paths_of(0) == list(range(10))
+    even = _graph_with_counts([50] * 8)
+    plan = hip.ShardPlan(even, 800, 4)
+    assert [plan.paths_of(r) for r in range(4)] == [[0, 1], [2, 3], [4, 5], [6, 7]]            # consecutive blocks
+    assert [int(q) for q in plan.quotas] == [200] * 4
+    # more ranks than paths: the surplus ranks own nothing and get no updates
+    plan = hip.ShardPlan(_graph_with_counts([10, 10, 10]), 30, 4)
+    assert sorted(int(q) for q in plan.quotas) == [0, 10, 10, 10] and int(plan.quotas.sum()) == 30
+
+
+def test_exchange_plan_spans_and_shared_slots():
+    """gfs_exchange_plan: windows over a chain — each rank's paths touch one span of the shared layout; only the
+    overlaps are exchanged; every touched slot has exactly one designated owner (the lowest covering rank)."""
+    from gfasort_amd import hip
+    g = G.synth_windows(10_000, 8, 2_000, 3, shuffle=False)            # path p covers nodes o_p .. o_p + 2000
+    plan = hip.ShardPlan(g, 1000, 4)
+    assert np.array_equal(plan.perm, np.arange(g.n_nodes))               # already in path order
+    first = g.path_first_step.astype(int)
+    for r in range(4):
+        nodes = np.concatenate([g.step_node[first[p]:first[p + 1]] for p in plan.paths_of(r)])
+        assert (int(plan.span_lo[r]), int(plan.span_hi[r])) == (int(nodes.min()), int(nodes.max()) + 1)
+    cover = np.zeros(g.n_nodes, dtype=int)
+    for r in range(4):
+        cover[int(plan.span_lo[r]):int(plan.span_hi[r])] += 1
+    shared = np.zeros(g.n_nodes, dtype=bool)
+    for lo, hi in plan.shared:
+        shared[lo:hi] = True
+    assert np.array_equal(shared, cover >= 2) and 0 < shared.sum() < g.n_nodes
+    owner = np.full(g.n_nodes, -1)
+    for lo, hi, r in plan.owned:
+        assert (owner[lo:hi] == -1).all()
+        owner[lo:hi] = r
+    assert ((owner >= 0) == (cover >= 1)).all()
+    for r in range(4):
+        mine = owner == r
+        assert (mine[:int(plan.span_lo[r])] == False).all() and (mine[int(plan.span_hi[r]):] == False).all()
+    whole = hip.ShardPlan(g, 1000, 4, whole_vector=True)
+    assert whole.shared == [(0, g.n_nodes)]
 
 
 def test_shard_quotas_sum_exactly():
