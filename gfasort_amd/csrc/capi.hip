@@ -199,6 +199,74 @@ int gfs_init_layout_dim0(const gfs_graph_view *g, uint64_t D, double *c) { // sg
     return GFS_OK;
 }
 
+// rand_distr 0.5 StandardNormal (f64) on Xoshiro256+ — the 256-layer ziggurat, restated from the crate's published
+// algorithm; its tables are rebuilt by the construction of the crate's generator script (R, V below).  PARITY UNPINNED
+// (DESIGN.md §5): neither the crate nor its table literals are in the container.
+namespace {
+constexpr double kZigR = 3.6541528853610088, kZigV = 0.00492867323399;
+struct ZigTables {
+    double x[257], f[257];
+    ZigTables() {
+        x[0] = kZigV / std::exp(-kZigR * kZigR / 2.0);
+        x[1] = kZigR;
+        for (int i = 1; i < 256; ++i) x[i + 1] = std::sqrt(-2.0 * std::log(kZigV / x[i] + std::exp(-x[i] * x[i] / 2.0)));
+        x[256] = 0.0;
+        for (int i = 0; i <= 256; ++i) f[i] = std::exp(-x[i] * x[i] / 2.0);
+    }
+};
+struct Xo256p {                                                            // rand_xoshiro 0.7 Xoshiro256Plus
+    uint64_t s[4];
+    explicit Xo256p(uint64_t seed) { for (auto &w : s) w = splitmix64(seed); }   // seed_from_u64
+    uint64_t next() {
+        const uint64_t r = s[0] + s[3], t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = (s[3] << 45) | (s[3] >> 19);
+        return r;
+    }
+};
+inline double float_with_exponent(uint64_t fraction52, int e) {
+    const uint64_t b = fraction52 | ((uint64_t)(1023 + e) << 52);
+    double d; std::memcpy(&d, &b, 8); return d;
+}
+inline double open01(Xo256p &g) { return float_with_exponent(g.next() >> 12, 0) - (1.0 - 2.220446049250313e-16 / 2.0); }
+double standard_normal(Xo256p &g) {
+    static const ZigTables T;
+    for (;;) {
+        const uint64_t bits = g.next();
+        const unsigned i = (unsigned)(bits & 0xff);
+        const double u = float_with_exponent(bits >> 12, 1) - 3.0;               // [-1, 1)
+        const double x = u * T.x[i];
+        if (std::fabs(x) < T.x[i + 1]) return x;
+        if (i == 0) {                                                          // the tail beyond R
+            double tx = 1.0, ty = 0.0;
+            while (-2.0 * ty < tx * tx) {
+                const double x_ = open01(g), y_ = open01(g);
+                tx = std::log(x_) / kZigR; ty = std::log(y_);
+            }
+            return u < 0.0 ? tx - kZigR : kZigR - tx;
+        }
+        const double r = (double)(g.next() >> 11) * (1.0 / 9007199254740992.0);  // rng.random::<f64>()
+        if (T.f[i + 1] + (T.f[i] - T.f[i + 1]) * r < std::exp(-x * x / 2.0)) return x;
+    }
+}
+}  // namespace
+
+// The whole start of path_linear_sgd_layout (sgd.rs:829-853): one generator seeded `seed`; per node the + end's
+// dimensions 1..D-1, then the - end's, each StandardNormal * sqrt(2N); dimension 0 as gfs_init_layout_dim0.
+int gfs_init_layout(const gfs_graph_view *g, uint64_t D, uint64_t seed, double *c) {
+    if (!g || (!c && g->n_nodes) || D == 0) return fail(GFS_E_ARG, "bad argument");
+    Xo256p rng(seed);                                                          // :829
+    const double sqrt_n = std::sqrt((double)g->n_nodes * 2.0);                 // :836
+    uint64_t len = 0;
+    for (uint64_t i = 0; i < g->n_nodes; ++i) {
+        c[i * 2 * D + 0] = (double)len;                                        // :839
+        for (uint64_t d = 1; d < D; ++d) c[i * 2 * D + d] = standard_normal(rng) * sqrt_n;          // :840-843
+        c[i * 2 * D + D] = (double)(len + g->node_len[i]);                     // :846
+        for (uint64_t d = 1; d < D; ++d) c[i * 2 * D + D + d] = standard_normal(rng) * sqrt_n;      // :847-850
+        len += g->node_len[i];
+    }
+    return GFS_OK;
+}
+
 int gfs_sort_order(const double *x, uint64_t n, uint64_t *order) {         // sgd.rs:665-671
     if ((!x || !order) && n) return fail(GFS_E_ARG, "null argument");
     std::iota(order, order + n, (uint64_t)0);

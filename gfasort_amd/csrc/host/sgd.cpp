@@ -242,25 +242,12 @@ static uint64_t splitmix64(uint64_t &s) {
 }
 
 std::vector<double> default_layout_init(const FlatGraph &f, size_t D, uint64_t seed) {
+    // the reference's own start (sgd.rs:829-853): dimension 0 = bp prefix, dimensions >= 1 = StandardNormal * sqrt(2N)
+    // from one Xoshiro256+ seeded `seed` (gfs_init_layout restates rand_distr's ziggurat: parity unpinned)
     const size_t N = f.node_len.size(), n = N * 2 * D;
     std::vector<double> c(n, 0.0);
-    if (D > 1) {
-        // r[k] = k-th output of SplitMix64(seed): the state advances by a constant, so any k is addressable
-        auto draw = [seed](uint64_t k) { uint64_t st = seed + k * 0x9E3779B97F4A7C15ull; return splitmix64(st); };
-        const double scale = std::sqrt(2.0 * (double)N);             // sgd.rs:836
-        const size_t BLOCK = 1 << 16;
-        parallel_for((n + BLOCK - 1) / BLOCK, [&](size_t b) {
-            for (size_t k = b * BLOCK; k < std::min(n, (b + 1) * BLOCK); ++k) {
-                double u1 = ((double)(draw(k) >> 11) + 1.0) / 9007199254740993.0;
-                double u2 = (double)(draw(n + k) >> 11) / 9007199254740992.0;
-                c[k] = std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2) * scale;
-            }
-        });
-    }
     gfs_graph_view v = f.view();
-    std::vector<double> c0(n);
-    gfs_init_layout_dim0(&v, D, c0.data());                          // sgd.rs:839,846
-    for (size_t i = 0; i < N; ++i) { c[i * 2 * D] = c0[i * 2 * D]; c[i * 2 * D + D] = c0[i * 2 * D + D]; }
+    gfs_init_layout(&v, D, seed, c.data());
     return c;
 }
 

@@ -198,14 +198,19 @@ __device__ __forceinline__ bool fused_trip(const KArgs &a, TeamState &ts, const 
             }
         }
         // the +r of the lane whose partner I am
+        // (every shuffle is a statement of its own: inside `a && __shfl(..)` or `c ? x : __shfl(..)` the compiler may run it
+        // only on the lanes that need the result, and a SOURCE lane that is switched off then supplies nothing)
         const double rv = shfl_f64(r_x, srcc);
-        const bool recv = src >= 0 && src <= 63 && __shfl((int)valid, srcc, 64) != 0;
+        const int vsrc = __shfl((int)valid, srcc, 64);
+        const bool recv = src >= 0 && src <= 63 && vsrc != 0;
         // a lane acts or receives in a colour, never both (its group's parity decides)
         if (valid) xo = xo - r_x;                                                      // :575  x[i] - r_x
         if (recv) xo = xo + rv;                                                        // :576  x[j] + r_x
+        const bool o1f = valid || recv, o2f = valid && out;
+        const double o1v = valid ? -r_x : rv;
         if (!(a.dbg & 1u)) {
-            if (valid) add_pos(x + node, -r_x); else if (recv) add_pos(x + node, rv);
-            if (valid && out) add_pos(x + pnode, r_x);
+            if (o1f) add_pos(x + node, o1v);
+            if (o2f) add_pos(x + pnode, r_x);
         }
         if (colour == 0 && wave_done >= wave_quota) return false;
     }

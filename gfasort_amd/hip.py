@@ -85,7 +85,7 @@ TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)
 # every symbol include/gfasort_hip.h declares
 EXPORTS = [
     "gfs_version", "gfs_last_error", "gfs_device_count", "gfs_warmup", "gfs_fast_precise_pow", "gfs_sgd_schedule",
-    "gfs_zeta_table_len", "gfs_zeta_table", "gfs_init_positions", "gfs_init_layout_dim0",
+    "gfs_zeta_table_len", "gfs_zeta_table", "gfs_init_positions", "gfs_init_layout_dim0", "gfs_init_layout",
     "gfs_sort_order", "gfs_path_linear_sgd", "gfs_path_sgd_sort", "gfs_path_linear_sgd_layout", "gfs_ctx_create",
     "gfs_ctx_create_with_layout", "gfs_ctx_node_layout",
     "gfs_ctx_destroy", "gfs_ctx_setup_1d", "gfs_ctx_setup_nd", "gfs_ctx_positions_len", "gfs_ctx_init_positions",
@@ -247,6 +247,14 @@ def init_layout_dim0(g, dims, coords=None):
     if coords is None:
         coords = np.zeros(g.n_nodes * 2 * dims, dtype=np.float64)
     check(lib().gfs_init_layout_dim0(C.byref(v), C.c_uint64(dims), _ptr(coords)))
+    return coords
+
+
+def init_layout(g, dims, seed):
+    """gfs_init_layout: the reference's whole layout start (dimension 0 + StandardNormal dimensions), Layout order."""
+    v, keep = make_view(g)
+    coords = np.zeros(g.n_nodes * 2 * dims, dtype=np.float64)
+    check(lib().gfs_init_layout(C.byref(v), C.c_uint64(dims), C.c_uint64(seed), _ptr(coords)))
     return coords
 
 

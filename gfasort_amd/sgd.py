@@ -46,22 +46,11 @@ def sgd_sort_only(graph: FlatGraph, params: PathSGDParams, verbose: int = 0, cfg
 
 
 def default_layout_init(graph: FlatGraph, dims: int, seed: int) -> np.ndarray:
-    """Initial coordinates in Layout order.  Dimension 0 exactly as sgd.rs:832-853 (+end =
-    bp prefix, -end = prefix + length).  Dimensions >= 1: N(0,1)*sqrt(2N) like sgd.rs:836-849,
-    but drawn by Box-Muller from SplitMix64(seed) — the reference's rand_distr ziggurat stream
-    is not reproduced."""
-    from .graph import splitmix64_array
-    n = graph.n_nodes * 2 * dims
-    c = np.zeros((graph.n_nodes, 2, dims), dtype=np.float64)
-    if dims > 1:
-        r = splitmix64_array(seed, 2 * n)
-        u1 = ((r[:n] >> np.uint64(11)).astype(np.float64) + 1.0) / 9007199254740993.0
-        u2 = (r[n:] >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
-        z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
-        c[:] = (z * np.sqrt(2.0 * graph.n_nodes)).reshape(graph.n_nodes, 2, dims)
-    c0 = hip.init_layout_dim0(graph, dims).reshape(graph.n_nodes, 2, dims)
-    c[:, :, 0] = c0[:, :, 0]
-    return np.ascontiguousarray(c.reshape(-1))
+    """Initial coordinates in Layout order, as the reference draws them (sgd.rs:829-853): dimension 0 = bp prefix
+    (+ end) / prefix + length (- end); dimensions >= 1 = StandardNormal * sqrt(2N) from ONE Xoshiro256+ seeded `seed`,
+    node by node.  gfs_init_layout restates rand_distr's ziggurat from its published algorithm: parity unpinned
+    (DESIGN.md §5)."""
+    return hip.init_layout(graph, dims, seed)
 
 
 def path_linear_sgd_layout(graph: FlatGraph, params: LayoutSGDParams, init: Optional[np.ndarray] = None,

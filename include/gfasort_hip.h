@@ -159,8 +159,12 @@ int      gfs_zeta_table(const gfs_sgd_params *p, double *zetas);
 /* initial positions x[idx] = bp prefix in node_order                      sgd.rs:271-294 */
 int      gfs_init_positions(const gfs_graph_view *g, double *x);
 /* layout init, dimension 0 only (+end = prefix, -end = prefix+len), Layout order; the
- * Gaussian dimensions >=1 (rand_distr StandardNormal, sgd.rs:829-850) are the caller's.    */
+ * Gaussian dimensions >=1 (rand_distr StandardNormal, sgd.rs:829-850): gfs_init_layout, or the caller's.   */
 int      gfs_init_layout_dim0(const gfs_graph_view *g, uint64_t dims, double *coords);
+/* the reference's whole layout start (sgd.rs:829-853): dimension 0 as above, dimensions >= 1 = StandardNormal * sqrt(2N)
+ * from ONE Xoshiro256+ seeded `seed`, drawn node by node (+ end, then - end).  rand_distr's ziggurat is restated from
+ * its published algorithm with rebuilt tables: parity unpinned.                                       */
+int      gfs_init_layout(const gfs_graph_view *g, uint64_t dims, uint64_t seed, double *coords);
 /* positions -> rank order (ascending, ties by dense index)                sgd.rs:665-671 */
 int      gfs_sort_order(const double *x, uint64_t n, uint64_t *order);
 

@@ -211,6 +211,73 @@ void gfo_init_layout_dim0(const gfo_graph *g, uint64_t D, double *c) {   /* sgd.
 }
 
 /* ------------------------------------------------------------------------------------------
+ * rand_distr 0.5 `StandardNormal` for f64 (sgd.rs:830,841,848) — an un-vendored crate, restated from its
+ * published algorithm: the 256-layer ziggurat of Marsaglia & Tsang as rand_distr implements it.  PARITY UNPINNED: the
+ * crate's source and its table literals are not in the container; the tables are rebuilt here by the construction the
+ * crate's generator script uses (R = 3.6541528853610088, V = 0.00492867323399; x[0] = V/f(R), x[1] = R,
+ * x[i+1] = f_inv(V/x[i] + f(x[i])), x[256] = 0; f = exp(-x^2/2)), which reproduces the literals if libm agrees with the
+ * Python that printed them.
+ *   loop: bits = next_u64; i = bits & 0xff; u = float_with_exponent(bits >> 12, 1) - 3.0  in [-1, 1);  x = u * X[i];
+ *         |x| < X[i+1] -> x;  i == 0 -> tail;  F[i+1] + (F[i] - F[i+1]) * random::<f64>() < exp(-x^2/2) -> x
+ *   tail: do { x = ln(Open01) / R; y = ln(Open01) } while (-2y < x^2);  u < 0 ? x - R : R - x
+ *   Open01: float_with_exponent(next_u64 >> 12, 0) - (1 - EPSILON/2)
+ * ---------------------------------------------------------------------------------------- */
+#define ZIG_R 3.6541528853610088
+#define ZIG_V 0.00492867323399
+static double zig_x[257], zig_f[257];
+static int zig_ready = 0;
+static void zig_build(void) {
+    if (zig_ready) return;
+    zig_x[0] = ZIG_V / exp(-ZIG_R * ZIG_R / 2.0);
+    zig_x[1] = ZIG_R;
+    for (int i = 1; i < 256; i++) zig_x[i + 1] = sqrt(-2.0 * log(ZIG_V / zig_x[i] + exp(-zig_x[i] * zig_x[i] / 2.0)));
+    zig_x[256] = 0.0;
+    for (int i = 0; i <= 256; i++) zig_f[i] = exp(-zig_x[i] * zig_x[i] / 2.0);
+    zig_ready = 1;
+}
+static inline double float_with_exponent(uint64_t fraction52, int e) { return bits_f64(fraction52 | ((uint64_t)(1023 + e) << 52)); }
+static inline double open01(uint64_t rng[4]) {
+    return float_with_exponent(gfo_xoshiro_next(rng) >> 12, 0) - (1.0 - 2.220446049250313e-16 / 2.0);
+}
+void gfo_ziggurat_tables(double *x257, double *f257) {
+    zig_build();
+    memcpy(x257, zig_x, sizeof zig_x); memcpy(f257, zig_f, sizeof zig_f);
+}
+double gfo_standard_normal(uint64_t rng[4]) {
+    zig_build();
+    for (;;) {
+        const uint64_t bits = gfo_xoshiro_next(rng);
+        const unsigned i = (unsigned)(bits & 0xff);
+        const double u = float_with_exponent(bits >> 12, 1) - 3.0;
+        const double x = u * zig_x[i];
+        if (fabs(x) < zig_x[i + 1]) return x;
+        if (i == 0) {
+            double tx = 1.0, ty = 0.0;
+            while (-2.0 * ty < tx * tx) {
+                const double x_ = open01(rng), y_ = open01(rng);
+                tx = log(x_) / ZIG_R; ty = log(y_);
+            }
+            return u < 0.0 ? tx - ZIG_R : ZIG_R - tx;
+        }
+        if (zig_f[i + 1] + (zig_f[i] - zig_f[i + 1]) * gfo_random_f64(rng) < exp(-x * x / 2.0)) return x;
+    }
+}
+/* the whole start of path_linear_sgd_layout (sgd.rs:829-853): ONE generator seeded `seed`; per node: + end dims 1..D-1,
+ * then - end dims 1..D-1; dim 0 = bp prefix / prefix + length.  coords in Layout order [node][end][dim]. */
+void gfo_init_layout(const gfo_graph *g, uint64_t D, uint64_t seed, double *c) {
+    uint64_t rng[4]; gfo_xoshiro_seed(seed, rng);                     /* :829 */
+    const double sqrt_n = sqrt((double)g->n_nodes * 2.0);             /* :836 */
+    uint64_t len = 0;
+    for (uint64_t i = 0; i < g->n_nodes; i++) {
+        c[i * 2 * D + 0] = (double)len;                               /* :839 */
+        for (uint64_t d = 1; d < D; d++) c[i * 2 * D + d] = gfo_standard_normal(rng) * sqrt_n;          /* :840-843 */
+        c[i * 2 * D + D] = (double)(len + g->node_len[i]);            /* :846 */
+        for (uint64_t d = 1; d < D; d++) c[i * 2 * D + D + d] = gfo_standard_normal(rng) * sqrt_n;      /* :847-850 */
+        len += g->node_len[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Internal PathIndex in two representations.
  *  reference-like: four 8-byte arrays + PathInfo + a hash map handle->idx (sgd.rs:14-31,272)
  *  flat          : 16-byte step records + 16-byte path records, dense idx stored in the step

@@ -98,6 +98,10 @@ void     gfo_path_index(const gfo_graph *g, uint64_t *step_pos, uint32_t *step_p
 void     gfo_init_positions(const gfo_graph *g, double *x);
 /* layout init dim 0 (sgd.rs:832-853); dims>=1 are caller-supplied (rand_distr ziggurat not restated) */
 void     gfo_init_layout_dim0(const gfo_graph *g, uint64_t dims, double *coords /* Layout order */);
+/* rand_distr StandardNormal (ziggurat) restated — PARITY UNPINNED, see gfs_oracle.c — and the full layout start */
+void     gfo_ziggurat_tables(double *x257, double *f257);
+double   gfo_standard_normal(uint64_t rng[4]);
+void     gfo_init_layout(const gfo_graph *g, uint64_t dims, uint64_t seed, double *coords /* Layout order */); /* sgd.rs:829-853 */
 
 /* ---- deterministic mode: n_streams Xoshiro streams (seed+t, = reference worker tid),
  * advanced round-robin one attempt each; stream t performs exactly its quota of successful

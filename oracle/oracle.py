@@ -177,6 +177,26 @@ def init_positions(g):
     return x
 
 
+def init_layout(g, dims, seed):
+    """sgd.rs:829-853 with the restated rand_distr StandardNormal (parity unpinned)."""
+    c = np.zeros(len(g.node_len) * 2 * dims, dtype=np.float64)
+    lib().gfo_init_layout(g.ref, C.c_uint64(dims), C.c_uint64(seed), _ptr(c))
+    return c
+
+
+def ziggurat_tables():
+    x, f = np.zeros(257), np.zeros(257)
+    lib().gfo_ziggurat_tables(_ptr(x), _ptr(f))
+    return x, f
+
+
+def standard_normal(seed, n):
+    rng = (C.c_uint64 * 4)()
+    lib().gfo_xoshiro_seed(seed, rng)
+    lib().gfo_standard_normal.restype = C.c_double
+    return np.array([lib().gfo_standard_normal(rng) for _ in range(n)])
+
+
 def init_layout_dim0(g, dims, coords=None):
     if coords is None:
         coords = np.zeros(g.c.n_nodes * 2 * dims, dtype=np.float64)

@@ -392,3 +392,54 @@ def test_golden_sgd_runs(golden):
     rc, st, tr = O.sgd_nd(oracle_graph(g), oracle_params(p), c, n_streams=1, trace_per_stream=8)
     assert (st.term_updates, st.attempts) == (ent["term_updates"], ent["attempts"])
     assert _hex(c[:32]) == ent["coords_head"] and hashlib.sha256(c.tobytes()).hexdigest() == ent["coords_sha256"]
+
+
+# ---- rand_distr StandardNormal (ziggurat), restated: PARITY UNPINNED (the crate is not in the container) ------------
+def test_ziggurat_tables_follow_the_published_construction():
+    """256 layers of equal area V under exp(-x^2/2), x[1] = R, x[256] = 0; x[0] = V / f(R) (the base strip's virtual
+    width).  3.910757959537090045 / 3.449278298560964462 / 0.000477467764586655 are the first table literals of
+    rand_distr's ziggurat_tables.rs as remembered — not read from the crate here."""
+    x, f = O.ziggurat_tables()
+    R, V = 3.6541528853610088, 0.00492867323399
+    assert x[1] == R and x[256] == 0.0 and f[256] == 1.0
+    assert abs(x[0] - 3.910757959537090045) < 1e-14 and abs(x[2] - 3.449278298560964462) < 1e-14
+    assert abs(f[0] - 0.000477467764586655) < 1e-17
+    assert np.all(np.diff(x) < 0) and np.all(np.diff(f) > 0)
+    assert np.allclose(f, np.exp(-x * x / 2.0), rtol=0, atol=1e-15)            # (numpy exp and libm exp differ by an ulp)
+    areas = x[1:256] * (f[2:257] - f[1:256])                      # every strip above the base has area V
+    assert np.abs(areas - V).max() < 1e-10
+
+
+def test_standard_normal_statistics_and_stream_use():
+    z = O.standard_normal(2024, 400_000)
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.01
+    assert abs(((z - z.mean()) ** 4).mean() / z.var() ** 2 - 3.0) < 0.05
+    from math import erf, sqrt
+    for t in (1.0, 2.0, 3.0):
+        want = 1.0 - erf(t / sqrt(2.0))
+        assert abs((np.abs(z) > t).mean() - want) < 5.0 * np.sqrt(want / z.shape[0])
+    # the common case consumes exactly one u64: i = low 8 bits, u from the top 52
+    rng = O.Xoshiro(seed=99)
+    bits = rng.next_u64()
+    x, f = O.ziggurat_tables()
+    i = bits & 0xFF
+    u = np.frombuffer(np.uint64((bits >> 12) | (1024 << 52)).tobytes(), dtype=np.float64)[0] - 3.0
+    if abs(u * x[i]) < x[i + 1]:
+        assert O.standard_normal(99, 1)[0] == u * x[i]
+
+
+@pytest.mark.parametrize("name", ["simple.gfa", "lil.gfa", "DRB1-3123.gfa"])
+def test_layout_start_product_equals_oracle_and_follows_the_reference_draw_order(name):
+    """sgd.rs:829-853: one generator; per node the + end's dims 1..D-1, then the - end's; dim 0 = prefix / prefix + len."""
+    from gfasort_amd import hip, sgd as S
+    g = load(name)
+    og = oracle_graph(g)
+    for D in (1, 2, 3):
+        c = hip.init_layout(g, D, 9399220)
+        assert np.array_equal(c.view(np.uint64), O.init_layout(og, D, 9399220).view(np.uint64))
+        assert np.array_equal(S.default_layout_init(g, D, 9399220), c)
+        c3 = c.reshape(g.n_nodes, 2, D)
+        assert np.array_equal(c3[:, :, 0].reshape(-1), O.init_layout_dim0(og, 1))
+        if D > 1:
+            z = O.standard_normal(9399220, g.n_nodes * 2 * (D - 1)) * np.sqrt(2.0 * g.n_nodes)
+            assert np.array_equal(c3[:, :, 1:].reshape(-1), z)       # node-major, + end first, dims ascending
