@@ -449,7 +449,9 @@ static int choose_bundle(gfs_ctx *c, int dims) {
     // short distances — for the oracle's mirror and on the GPU (profiles/r02/quality_probe_long_runs.log).
     uint32_t k = (c->cfg.flags >> 24) & 0xFFu;
     if (k > 64 || (k & (k - 1))) return fail(GFS_E_ARG, "GFS_F_CHAIN: the run length in trips must be a power of two <= 64");
-    if (k == 0) k = 64;
+    // (layout kernels: 16 — on C4 runs of 64 trips cost 13 % of the rate, 30.8 against 34.2-35.5 G updates/s, and the error
+    // profile of the 2-D layout is already below reference streams' at 16: profiles/r02/quality_probe_layout_k.log)
+    if (k == 0) k = dims ? 16 : 64;
     c->chain = b == 64 ? k : 1;                       // (nD: team kernels exist for D <= 3; checked above)
     return GFS_OK;
 }

@@ -411,7 +411,9 @@ __global__ void merge_prepare_kernel(const double *x, const double *x_prev, floa
             const double2 a = *reinterpret_cast<const double2 *>(x + k), b = *reinterpret_cast<const double2 *>(x_prev + k);
             const float d0 = (float)(a.x - b.x), d1 = (float)(a.y - b.y);
             *reinterpret_cast<float2 *>(buf + k) = make_float2(d0, d1);
-            *reinterpret_cast<float2 *>(buf + n + k) = make_float2(d0 != 0.f ? 1.f : 0.f, d1 != 0.f ? 1.f : 0.f);
+            // the touched row starts at buf + n: 8-byte aligned only when n is even
+            if (n & 1) { buf[n + k] = d0 != 0.f ? 1.f : 0.f; buf[n + k + 1] = d1 != 0.f ? 1.f : 0.f; }
+            else *reinterpret_cast<float2 *>(buf + n + k) = make_float2(d0 != 0.f ? 1.f : 0.f, d1 != 0.f ? 1.f : 0.f);
         } else {
             const float d = (float)(x[k] - x_prev[k]);
             buf[k] = d; buf[n + k] = d != 0.f ? 1.f : 0.f;

@@ -24,11 +24,11 @@ struct TripND {
     uint64_t sa = 0, sb = 0, first = 0;
     uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0), na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
     uint32_t cnt = 0, flips = 0, k = 1, off = 0;
-    bool valid = false, two = false;
+    bool valid = false, two = false, fused = false;   // fused: both colours of a short-jump trip in this one (fused_trip_nd)
     int mshift = 0;
 };
 
-template <int B>
+template <int B, bool FUSE>
 __device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, uint32_t lflips, int t, uint32_t seg, uint32_t colour,
                                                int sub, int q, TripND &tr) {
     constexpr int RUNS = 64 / B;
@@ -42,11 +42,172 @@ __device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, 
     const bool two = !(a.dbg & 0x08u) && two_colour<B>(ok, tr.cnt, ra0, rb0);
     tr.two = B == 64 ? two : (__any(two) != 0);
     tr.ra = make_uint4(0, 0, 0, 0); tr.rb = tr.ra; tr.na = tr.ra; tr.nb = tr.ra;
+    tr.fused = FUSE && B == 64 && tr.mshift != 0 && colour == 0 && two && !(a.dbg & 0x100u);
+    if (tr.fused) {
+        // every lane takes its own step of the trip, its partner's record and the two records after them (node lengths)
+        const int dst = sub + tr.mshift;
+        tr.sa = tr.first + merged_trip_base(tr.cnt, ra0, tr.off) + (uint32_t)sub;
+        tr.sb = (uint64_t)((int64_t)tr.sa + tr.mshift);
+        tr.valid = dst < 0 || dst > 63;                                // partner beyond the trip's 64 steps
+        tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb];
+        tr.na = a.step_rec[tr.sa + 1u < a.n_steps ? tr.sa + 1u : tr.sa];
+        tr.nb = a.step_rec[tr.sb + 1u < a.n_steps ? tr.sb + 1u : tr.sb];
+        return;
+    }
     if (tr.valid) {
         tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb];
         tr.na = a.step_rec[tr.sa + 1u < a.n_steps ? tr.sa + 1u : tr.sa];
         tr.nb = a.step_rec[tr.sb + 1u < a.n_steps ? tr.sb + 1u : tr.sb];
     }
+}
+
+// The adds of one trip, D >= 2.  The D coordinates of an end are adjacent (8*D bytes) and so are the same ends of
+// neighbouring nodes.  Each lane brings up to two adds (A, B: pointer to an end's coordinates, D values, flag); they are
+// re-dealt so that a group of P = 2 (D=2) or 4 (D=3) adjacent lanes of one instruction carries the D coordinates of the
+// SAME end: one instruction then covers 64/P neighbouring nodes = 512 (384 for D=3) contiguous bytes = 8-9 (6-7)
+// requests.  Wave-uniform control flow: all lanes take part in the shuffles.
+template <int D>
+__device__ __forceinline__ void issue_adds_regrouped(const int lane, const double (&vA)[D], const double (&vB)[D],
+                                                     const unsigned long long pA, const unsigned long long pB, const int fA, const int fB) {
+    constexpr int P = D <= 2 ? 2 : 4;
+    const int d = lane & (P - 1);
+#pragma unroll
+    for (int pass = 0; pass < P; ++pass) {
+        const int m = pass * (64 / P) + lane / P;
+        double va = 0.0, vb = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double ak = __shfl(vA[k], m, 64), bk = __shfl(vB[k], m, 64);
+            if (k == d) { va = ak; vb = bk; }
+        }
+        const unsigned long long pa = __shfl(pA, m, 64), pb = __shfl(pB, m, 64);
+        const int fa = __shfl(fA, m, 64), fb = __shfl(fB, m, 64);
+        if (d < D) {
+            if (fa) add_pos(reinterpret_cast<double *>(pa) + d, va);
+            if (fb) add_pos(reinterpret_cast<double *>(pb) + d, vb);
+        }
+    }
+}
+
+// FUSED short-jump trip of the layout kernel (D = 2, 3; B = 64; the trip and all its partners inside the path) — the nD
+// form of K1b's fused_trip (sgd_kernels_1d.hip).  A lane's step is the a-side of its own term in one colour and the
+// b-side of its neighbour's term in the other; the two roles take the end the run's flips select (sgd.rs:1062-1077), so
+// a lane keeps the coordinates of its a-end and of its b-end in registers (one set when both flips agree).  Partners
+// inside the trip are read from the lane that holds them; colour 1 computes on what colour 0 produced.  Same terms, same
+// arithmetic, same order as the two generic trips.  Returns false when the quota filled between the colours.
+template <int D, bool ATOMIC_LOADS, bool TRACE>
+__device__ __forceinline__ bool fused_trip_nd(const KArgs &a, const TripND &cur, const int lane, const uint32_t tid,
+                                              const uint64_t wave_quota, uint64_t &wave_done, uint32_t &done, uint32_t &att, uint32_t &ntr) {
+    const int s = cur.mshift, z = s < 0 ? -s : s;
+    const int dst = lane + s, src = lane - s;
+    const bool out = cur.valid;
+    const int dstc = out ? lane : dst, srcc = (src < 0 || src > 63) ? lane : src;
+    const uint32_t grp = ((cur.off + (uint32_t)lane) / (uint32_t)z) & 1u;
+    const bool fa = (cur.flips & 1u) != 0u, fb = (cur.flips & 2u) != 0u;      // wave-uniform
+    const uint64_t last_step = cur.first + cur.cnt - 1u;
+    const uint64_t plen = a.path_len[rec_path(cur.ra)];
+    // my step in both roles
+    const uint64_t p_own = rec_pos_u64(cur.ra), e_own = cur.sa == last_step ? plen : rec_pos_u64(cur.na);
+    const bool rev_own = (cur.ra.y >> 31) != 0;
+    const double len_own = (double)(e_own - p_own);
+    const double pos_a = (double)p_own + (fa ? len_own : 0.0);                // sgd.rs:1047,1062-1064
+    const bool end_a = fa ? !rev_own : rev_own;
+    const bool end_b_own = fb ? !rev_own : rev_own;
+    // my partner's step as b-side (its record is loaded whether it sits inside the trip or not)
+    const uint64_t p_p = rec_pos_u64(cur.rb), e_p = cur.sb == last_step ? plen : rec_pos_u64(cur.nb);
+    const bool rev_p = (cur.rb.y >> 31) != 0;
+    const double pos_b = (double)p_p + (fb ? (double)(e_p - p_p) : 0.0);      // :1048,1071-1073
+    const bool end_b = fb ? !rev_p : rev_p;
+    const double term_dist = fabs(pos_a - pos_b);                             // :1080
+    const uint32_t node = cur.ra.x, pnode = cur.rb.x;
+    const bool term_ok = term_dist != 0.0 && node != 0xFFFFFFFFu && pnode != 0xFFFFFFFFu;
+    const uint64_t idx_i = (uint64_t)node * 2u + (end_a ? 1u : 0u), idx_j = (uint64_t)pnode * 2u + (end_b ? 1u : 0u);
+    const bool same = idx_i == idx_j;
+    const int crowd = crowd_shift<true>(a, cur.ra, cur.rb);
+    double *ptr_a = coord_ptr<D>(a, node == 0xFFFFFFFFu ? 0u : node, end_a);
+    double *ptr_bo = coord_ptr<D>(a, node == 0xFFFFFFFFu ? 0u : node, end_b_own);
+    double *ptr_p = coord_ptr<D>(a, pnode == 0xFFFFFFFFu ? 0u : pnode, end_b);
+    // coordinates: my a-end, my b-end (the same registers when the flips agree), my partner's b-end when it is outside
+    double ca[D], cb[D], cp[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { ca[d] = 0.0; cb[d] = 0.0; cp[d] = 0.0; }
+    if (node != 0xFFFFFFFFu) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) ca[d] = load_pos<ATOMIC_LOADS>(ptr_a + d);
+        if (fa != fb) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) cb[d] = load_pos<ATOMIC_LOADS>(ptr_bo + d);
+        }
+    }
+    if (out && pnode != 0xFFFFFFFFu) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) cp[d] = load_pos<ATOMIC_LOADS>(ptr_p + d);
+    }
+#pragma unroll
+    for (uint32_t colour = 0; colour < 2u; ++colour) {
+        ++att;
+        bool valid = term_ok && grp == colour;
+        const unsigned long long vmask = __ballot(valid);
+        const uint64_t remaining = wave_quota - wave_done;
+        const uint32_t nvalid = (uint32_t)__popcll(vmask);
+        if (valid && nvalid > remaining) valid = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull)) < remaining;
+        wave_done += nvalid < remaining ? nvalid : remaining;
+        // my partner's CURRENT b-end coordinates (each shuffle a statement of its own, see fused_trip)
+        double cj[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double from_a = __shfl(ca[d], dstc, 64), from_b = __shfl(cb[d], dstc, 64);
+            cj[d] = out ? cp[d] : (fa != fb ? from_b : from_a);
+        }
+        double r_d[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) r_d[d] = 0.0;
+        if (valid) {
+            double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd);  // :1085-1086
+            double deltas[D], mag_sq = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { deltas[d] = ca[d] - cj[d]; mag_sq += deltas[d] * deltas[d]; }   // :1108-1113
+            if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }           // :1116-1119
+            const double mag = sqrt(mag_sq);                                   // :1121
+            const double delta = mu * (mag - term_dist) / 2.0;                 // :1125
+            const double r = delta / mag;                                      // :1142
+#pragma unroll
+            for (int d = 0; d < D; ++d) r_d[d] = r * deltas[d];
+            ++done;                                                            // :1151
+            if (TRACE) {
+                if (ntr < a.trace_per_stream) {
+                    TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                    tt->i = (uint32_t)idx_i; tt->j = (uint32_t)idx_j; tt->d = term_dist;
+                    ++ntr;
+                }
+            }
+        }
+        // the +r of the lane whose partner I am
+        double rv[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) rv[d] = __shfl(r_d[d], srcc, 64);
+        const int vsrc = __shfl((int)valid, srcc, 64);
+        const bool recv = src >= 0 && src <= 63 && vsrc != 0;
+        // registers: a lane acts (its a-end moves by -r) or receives (its b-end moves by +r) in a colour, never both
+        if (valid && !same) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) ca[d] = ca[d] - r_d[d];                // :1143-1146
+        }
+        if (recv) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) { if (fa != fb) cb[d] = cb[d] + rv[d]; else ca[d] = ca[d] + rv[d]; }   // :1147-1148
+        }
+        // the adds: A = my own end (acting: -r to the a-end; receiving: +r to the b-end), B = my partner's end when it lies
+        // outside the trip
+        double vA[D], vB[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { vA[d] = valid ? -r_d[d] : rv[d]; vB[d] = r_d[d]; }
+        const unsigned long long pA = (unsigned long long)(valid ? ptr_a : ptr_bo), pB = (unsigned long long)ptr_p;
+        const int fA = (valid && !same) || recv, fB = valid && out;
+        if (!(a.dbg & 1u)) issue_adds_regrouped<D>(lane, vA, vB, pA, pB, fA, fB);
+        if (colour == 0 && wave_done >= wave_quota) return false;
+    }
+    return true;
 }
 
 template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
@@ -77,16 +238,24 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
         const uint32_t lflips = rng.flip() | (rng.flip() << 1);            // the run's end flips: bit 0 = a, bit 1 = b
         int t = 0; uint32_t seg = 0, colour = 0;
         TripND cur;
-        expand_trip_nd<B>(a, L, lflips, t, seg, colour, sub, q, cur);
+        expand_trip_nd<B, (D >= 2)>(a, L, lflips, t, seg, colour, sub, q, cur);
         for (;;) {
             // the trip after this one (second colour, next trip of the run, next slot): request its records now
             int t_n = t; uint32_t colour_n = 0u, seg_n = seg;
-            if (colour == 0 && cur.two) colour_n = 1u;
+            if (colour == 0 && cur.two && !cur.fused) colour_n = 1u;
             else if (seg + 1u < cur.k) seg_n = seg + 1u;
             else { t_n = t + 1; seg_n = 0u; }
             const bool have_n = t_n < B;
             TripND nxt;
-            if (have_n) expand_trip_nd<B>(a, L, lflips, t_n, seg_n, colour_n, sub, q, nxt);
+            if (have_n) expand_trip_nd<B, (D >= 2)>(a, L, lflips, t_n, seg_n, colour_n, sub, q, nxt);
+            if (D >= 2 && B == 64 && cur.fused) {
+                // (a quota that fills between the colours ends the iteration: the pass is dropped in nD, and with it the
+                // second colour — as the generic form drops whatever is left of a pass)
+                if (!fused_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, done, att, ntr)) break;
+                if (wave_done >= wave_quota || !have_n) break;
+                cur = nxt; t = t_n; colour = colour_n; seg = seg_n;
+                continue;
+            }
             bool valid = cur.valid;
             const uint4 ra = cur.ra, rb = cur.rb, na = cur.na, nb = cur.nb;
             const uint64_t sa = cur.sa, sb = cur.sb, first = cur.first;
@@ -162,13 +331,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                 }
             }
             if (D >= 2) {
-                // The D coordinates of an end are adjacent (8*D bytes) and so are the same ends of neighbouring
-                // nodes.  Re-deal the 64 lanes' adds so that a group of P = 2 (D=2) or 4 (D=3) adjacent lanes
-                // of one instruction carries the D coordinates of the SAME end: one instruction then covers
-                // 64/P neighbouring nodes = 512 (384 for D=3) contiguous bytes = 8-9 (6-7) requests.
-                // Wave-uniform control flow: all lanes take part in the shuffles.
-                constexpr int P = D <= 2 ? 2 : 4;
-                // the two adds of this lane: A = -r to end i, B = +r to end j (:1143-1149)
+                // the two adds of this lane: A = -r to end i, B = +r to end j (:1143-1149), re-dealt (issue_adds_regrouped)
                 double vA[D], vB[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) { vA[k] = -upd_r[k]; vB[k] = upd_r[k]; }
@@ -194,23 +357,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
                     const int dst = lane + mshift;
                     fB = fB && (dst < 0 || dst > 63);                                  // partner beyond the run: add it myself
                 }
-                const int d = lane & (P - 1);
-#pragma unroll
-                for (int pass = 0; pass < P; ++pass) {
-                    const int m = pass * (64 / P) + lane / P;
-                    double va = 0.0, vb = 0.0;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double ak = __shfl(vA[k], m, 64), bk = __shfl(vB[k], m, 64);
-                        if (k == d) { va = ak; vb = bk; }
-                    }
-                    const unsigned long long pa = __shfl(pA, m, 64), pb = __shfl(pB, m, 64);
-                    const int fa = __shfl(fA, m, 64), fb = __shfl(fB, m, 64);
-                    if (d < D) {
-                        if (fa) add_pos(reinterpret_cast<double *>(pa) + d, va);
-                        if (fb) add_pos(reinterpret_cast<double *>(pb) + d, vb);
-                    }
-                }
+                issue_adds_regrouped<D>(lane, vA, vB, pA, pB, fA, fB);
             }
             if (wave_done >= wave_quota) break;                        // what is left of the pass is dropped (no carry-over in nD)
             if (!have_n) break;

@@ -19,7 +19,7 @@ F_DBG_NO_ALIGN, F_DBG_ALIGN_FIRST, F_DBG_WIDE_INDEX, F_DBG_NO_FUSED_TRIP = 0x100
 
 
 def F_CHAIN(k):
-    """GFS_F_CHAIN(k): longest run in trips at B = 64 (0 = auto = 64, else a power of two <= 64)."""
+    """GFS_F_CHAIN(k): longest run in trips at B = 64 (0 = auto: 64 for the 1D sort, 16 for layouts; else a power of two <= 64)."""
     return (int(k) & 0xFF) << 24
 
 

@@ -106,7 +106,8 @@ typedef struct gfs_launch_config {
  * graphs (< 16384 nodes), else up to 64 while an iteration still has >= 4096 independent draws. */
 #define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* n in {0 = auto, 1, 4, 8, 16, 32, 64} */
 /* Long runs: with bundles of 64 a sampled (step a, jump) is expanded over k consecutive trips of its wave, i.e. over
- * 64*k consecutive steps (k adapts downwards on short paths).  k = 0 (default): 64.  k = 1: a run is one trip. */
+ * 64*k consecutive steps (k adapts downwards on short paths).  k = 0 (default): 64 for the 1D sort, 16 for the layout
+ * kernels.  k = 1: a run is one trip. */
 #define GFS_F_CHAIN(k) (((uint32_t)(k) & 0xFFu) << 24)   /* k in {0 = auto, 1, 2, 4, 8, 16, 32, 64} */
 #define GFS_F_NO_FUSE       4u        /* gfs_ctx_run / gfs_ctx_run_range: one launch per iteration even where
                                          a fused persistent launch is possible                        */

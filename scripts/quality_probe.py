@@ -84,6 +84,9 @@ def study_layout(name, g, variants, dims=2, seeds=2):
             p.seed = 9399220 + 1000 * sd
             name_v, _, T = v.partition("@")
             rc, c, st = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(n_streams=int(T) if T else 0, flags=VARIANTS[name_v]))
+            if os.environ.get("LAYOUT_RATE_ONLY"):
+                print(f"  {v:10s} seed {sd} k {st.run_trips} {st.term_updates / (st.kernel_ms * 1e-3) / 1e9:6.2f} G/s", flush=True)
+                continue
             rate = st.term_updates / (st.kernel_ms * 1e-3) / 1e9
             s = O.layout_stress(og, dims, c, 200000)
             _, rms, cnt = Q.stress_by_scale(g, c, dims, 1_000_000)
@@ -96,6 +99,9 @@ def main():
     variants = sys.argv[2:] or ["B1", "B8", "B64"]
     if which in ("small", "both"):
         study("bubbles 400k sites x 24 hap", G.synth_bubbles(400_000, 24, 6), variants)
+    if which == "medium":
+        for sites, haps, seed in ((20_000, 16, 5), (60_000, 16, 8), (150_000, 24, 9)):
+            study(f"bubbles {sites} sites x {haps} hap", G.synth_bubbles(sites, haps, seed), variants)
     if which == "layout":
         study_layout("bubbles 400k sites x 24 hap", G.synth_bubbles(400_000, 24, 6), variants)
     if which == "c3":

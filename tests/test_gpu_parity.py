@@ -274,9 +274,10 @@ def _node_slots(g):
     return path_order_layout(g)
 
 
-def _mirror_chain(B):
-    """The product's default run length in trips (GFS_F_CHAIN auto): 64 at B = 64 (1D and layout), else one trip per run."""
-    return 64 if B == 64 else 1
+def _mirror_chain(B, dims=0):
+    """The product's default run length in trips (GFS_F_CHAIN auto) at B = 64: 64 for the 1D sort, 16 for layouts; else one
+    trip per run."""
+    return (16 if dims else 64) if B == 64 else 1
 
 
 
@@ -369,7 +370,7 @@ def test_bundled_nd_sampler_trace_matches_oracle_mirror(B, dims):
     og, op = oracle_graph(g), oracle_params(p)
     c0 = gaussian_init(g, dims, 11)
     c_ref = c0.copy()
-    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g), chain=_mirror_chain(B))
+    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g), chain=_mirror_chain(B, dims))
     st_o.run(c_ref)
     so = st_o.stats()
     ctx = hip.Context(g)
@@ -836,6 +837,57 @@ def test_initial_positions_on_the_device_equal_the_host_prefix_sum():
         ctx.close()
 
 
+# ---- f32 or f64 on the wire?  A C5-shaped graph: positions up to ~1e8 bp, two ranks sharing the one GPU -------------
+def _mp_rank_payload(rank, world, port, f64, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gfasort_amd.distributed import RankDriver
+    g = _big_position_windows()
+    p = _ygs(g, 100)
+    r = RankDriver(g, p, rank, world, dims=0, device_index=0, dist=dist, payload_f64=f64)
+    r.set_positions(None)
+    r.run()
+    torch.cuda.synchronize()
+    x = r.positions_numpy()
+    if rank == 0:
+        out.put((x, int(r.info.shared_slots), int(r.info.exchange_count)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _big_position_windows():
+    g = G.synth_windows(200_000, 32, 25_000, 9)
+    g.node_len = (g.node_len.astype(np.uint64) * 60).astype(np.uint32)        # 200k nodes x ~510 bp: positions to 1e8
+    return g
+
+
+@pytest.mark.parametrize("f64", [False, True])
+def test_exchange_payload_f32_and_f64_at_positions_of_1e8(f64):
+    """The exchange buffer carries MOVES (x - x_prev), not positions: f32 rounds a move to 24 bits whatever the position
+    is.  With positions up to 1e8 bp both payloads sort the chain exactly and agree with each other to ~1e-6 of the span."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_mp_rank_payload, args=(r, 2, port, f64, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    x, shared, count = out.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    g = _big_position_windows()
+    assert x.max() - x.min() > 5e7 and 0 < shared < g.n_nodes and count == 2 * shared
+    assert np.isfinite(x).all() and _chain_order_ok(g, x)
+    og = oracle_graph(g)
+    assert O.stress_1d(og, x, 100000) < 1e-6
+
+
 # ---- the N>1 path for the layout step: two ranks share the one GPU over gloo, D = 2 ------------------------------
 def _mp_rank_nd(rank, world, port, out):
     import os
@@ -931,7 +983,7 @@ def test_layout_team_kernel_single_wave_coords_equal_the_oracle_mirror(dims):
     og, op = oracle_graph(g), oracle_params(p)
     c0 = gaussian_init(g, dims, 5)
     c_ref = c0.copy()
-    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64))
+    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64, dims))
     st_o.run(c_ref)
     so = st_o.stats()
     ctx = hip.Context(g)
