@@ -20,7 +20,7 @@ HDRS    := $(CSRC)/sgd_device.h $(CSRC)/sgd_kernel_common.h include/gfasort_hip.
 HOSTSRC := $(HOST)/graph.cpp $(HOST)/sgd.cpp
 HOSTHDR := $(HOST)/graph.hpp $(HOST)/sgd.hpp
 
-all: $(LIB) $(BINDIR)/gfasort_hip $(BINDIR)/host_selftest oracle
+all: $(LIB) $(BINDIR)/gfasort_hip $(BINDIR)/host_selftest $(BINDIR)/multi_rank_selftest oracle
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
@@ -36,6 +36,10 @@ $(BINDIR)/gfasort_hip: $(HOST)/main.cpp $(HOSTSRC) $(HOSTHDR) $(LIB)
 $(BINDIR)/host_selftest: $(HOST)/selftest.cpp $(HOSTSRC) $(HOSTHDR) $(LIB)
 	@mkdir -p $(BINDIR)
 	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/selftest.cpp $(HOSTSRC) -L$(LIBDIR) -lgfasort_hip -pthread '-Wl,-rpath,$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+
+$(BINDIR)/multi_rank_selftest: $(HOST)/multi_selftest.cpp $(LIB)
+	@mkdir -p $(BINDIR)
+	$(HIPCC) -x hip --offload-arch=gfx950 -O2 -std=c++17 -o $@ $(HOST)/multi_selftest.cpp -L$(LIBDIR) -lgfasort_hip -pthread '-Wl,-rpath,$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle -s

@@ -60,6 +60,7 @@ HOST_HEADERS = ["graph.hpp", "sgd.hpp"]
 BINDIR = os.path.join(HERE, "bin")
 CLI = os.path.join(BINDIR, "gfasort_hip")
 SELFTEST = os.path.join(BINDIR, "host_selftest")
+MULTI_SELFTEST = os.path.join(BINDIR, "multi_rank_selftest")
 CXX_FLAGS = ["-O2", "-std=c++17", "-Wall", "-ffp-contract=off"]
 
 
@@ -79,6 +80,15 @@ def build_host(force=False, verbose=False):
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
         out.append(exe)
+    # multi_rank_selftest drives gfs_rank_* from one host thread per rank and stages its all-reduce through hipMemcpy: hipcc
+    src = os.path.join(HOST_DIR, "multi_selftest.cpp")
+    if force or not os.path.exists(MULTI_SELFTEST) or any(os.path.getmtime(d) > os.path.getmtime(MULTI_SELFTEST) for d in (src, LIB)):
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-o", MULTI_SELFTEST, src,
+               "-L" + LIBDIR, "-lgfasort_hip", "-pthread", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    out.append(MULTI_SELFTEST)
     return out
 
 
