@@ -23,7 +23,7 @@ hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_load
 hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
                            dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t warm_module_1d();
-hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables);
+hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu);
 hipError_t warm_module_nd();
 hipError_t warm_module_nd_team();
 hipError_t warm_module_index();
@@ -319,6 +319,7 @@ struct gfs_ctx {
     gfs::IterConsts *d_its = nullptr; uint64_t its_cap = 0;   // schedule slice of a fused launch (arbitrary lists)
     gfs::IterConsts *d_its_all = nullptr;                     // constants of iterations 0..=iter_max, resident
     uint64_t n_streams = 0, quota_total = 0;
+    uint64_t fused_resident_blocks = 0; // workgroups of the fused 1D kernel the chip holds at once (block size, LDS table)
     uint32_t block = 256;
     uint32_t bundle = 1;               // lanes per sampling bundle actually used (1 = reference streams)
     uint32_t chain = 1;                // longest run in trips (sgd_device.h run_trips); 1 = a run is one trip
@@ -401,7 +402,9 @@ static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
     // kernels (profiles/r01/sweep_streams_final.log, defer_probe.log): C3 69.1 / 78.7 / 80.2 G updates/s at 512 / 768 /
     // 976 lanes per CU, 600k nodes 66.7 / 75.6 / 77.7, C4 layout flat from 768 up; reference streams are flat within
     // 5 % from 512 up.  (976 rather than 1024 keeps 4*streams <= 1e6 nodes, the deferral condition, on C3-sized graphs.)
-    const uint64_t chip = (uint64_t)c->cu_count * 976;
+    // Round 2: the 1D team kernels are built for 5 waves per SIMD and get 1 280 lanes per CU (327 680 on MI355X): C3 77.5 G
+    // updates/s at 249 856 streams, 78.0 at 294 912, 80.0 at 327 680 (profiles/r02/streams_5_waves.log).
+    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1280 : 976);
     // keep >= 8 updates per stream per batch on small graphs
     const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
     // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight
@@ -505,6 +508,20 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     size_t lds = (size_t)c->n_paths * sizeof(uint4) + (size_t)c->zlen_staged * 8;
     c->lds_tables = !(c->cfg.flags & GFS_F_NO_LDS_TABLES) && lds <= 48 * 1024;
     c->lds_bytes = c->lds_tables ? lds : 0;
+    c->fused_resident_blocks = 0;
+    if (dims == 0 && c->bundle >= 16) {
+        // The fused launch has no grid barrier: a workgroup that does not fit on the chip beside the others would walk
+        // its whole schedule, early large-eta iterations included, after they have finished theirs — on a 525k-node graph
+        // 5 such waves of 4101 were enough to wreck the layout (relative error 64 at path distance 1:
+        // profiles/r02/streams_5_waves.log).  So the fused kernel is only launched with every workgroup resident: ask the
+        // runtime how many fit per CU with this block size and LDS table (33 KB of zeta table = 4 blocks of 256 per CU, not
+        // 5), bound the automatic stream count by it, and run one launch per iteration when a caller asks for more streams.
+        int per_cu = 0;
+        HIPCHK(gfs::prepare_1d_fused(c->bundle, c->lds_tables, (int)c->block, c->lds_bytes, &per_cu));   // (also: not inside the first launch's event bracket)
+        c->fused_resident_blocks = (uint64_t)std::max(per_cu, 0) * c->cu_count;
+        const uint64_t resident = c->fused_resident_blocks * c->block;
+        if (!c->cfg.n_streams && T > resident && resident >= 64) c->n_streams = T = resident;
+    }
 
     HIPCHK(hipMalloc(&c->d_rng, 4 * T * 8));
     if (dims == 0 && c->bundle > 1) {
@@ -525,7 +542,6 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
         for (uint64_t k = 0; k <= c->params.iter_max; ++k) iter_consts(c, k, all[k]);
         HIPCHK(hipMalloc(&c->d_its_all, all.size() * sizeof(gfs::IterConsts)));
         HIPCHK(hipMemcpy(c->d_its_all, all.data(), all.size() * sizeof(gfs::IterConsts), hipMemcpyHostToDevice));
-        HIPCHK(gfs::prepare_1d_fused(c->bundle, c->lds_tables));          // not inside the first launch's event bracket
     }
     c->configured = true;
     return GFS_OK;
@@ -849,7 +865,8 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     if (!c->valid_paths || c->n_nodes == 0) return GFS_NOTHING_TO_DO;
     for (uint64_t i = 0; i < n; ++i) if (ks[i] > c->params.iter_max) return fail(GFS_E_ARG, "iteration beyond iter_max");
     const bool can_fuse = c->dims == 0 && c->bundle >= 16 && c->atomic_loads && !c->d_trace && n > 1 && n <= 0xFFFFFFFFull &&
-                          !(c->cfg.flags & GFS_F_NO_FUSE);
+                          !(c->cfg.flags & GFS_F_NO_FUSE) &&
+                          (c->n_streams + c->block - 1) / c->block <= c->fused_resident_blocks;     // every workgroup resident
     if (!can_fuse) {
         for (uint64_t i = 0; i < n; ++i) { int rc = gfs_ctx_run_iteration(c, ks[i], hip_stream); if (rc) return rc; }
         return GFS_OK;

@@ -149,12 +149,15 @@ __device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v,
 // and positions of half the lanes and of their partners — which are the OTHER colour's lanes — and the second colour
 // reads what the first one wrote.  Here every lane loads its own record and position once; partners inside the run are
 // read from the lane that holds them (wave shuffles), colour 1 computes on the positions colour 0 has just produced in
-// registers (bit for bit what it would read back from memory when no other wave interferes), and each colour issues one
-// coalesced add per lane.  Same terms, same arithmetic, same order as the two trips.  What it buys is not speed (it is
-// 2-5 % slower than two trips) but precision under concurrency: both colours see ONE snapshot of the run's 64 nodes and
-// land within one memory round trip, instead of exposing the run to the other ~4 000 waves for two.  At one stream per
-// two nodes (525k-node bubble graph) the relative error at path distance 1 is 0.200 against 0.248 with two trips
-// (reference streams: 0.194; profiles/r02/quality_probe_long_runs.log).  Returns false when the wave's quota filled
+// registers (bit for bit what it would read back from memory when no other wave interferes), and a lane's node takes ONE
+// add for both colours — what it gave as the acting lane of one colour plus what it took as the partner in the other:
+// memory receives x + (-r + r') where two trips would make it (x - r) + r' (the oracle's mirror rounds the same way).
+// Same terms, same arithmetic, same order as the two trips.  It buys precision under concurrency — both colours see ONE
+// snapshot of the run's 64 nodes and land in one memory round trip, instead of exposing the run to the other ~5 000 waves
+// for two: at one stream per two nodes (525k-node bubble graph) the relative error at path distance 1 is 0.200 against
+// 0.248 with two trips (reference streams: 0.194; profiles/r02/quality_probe_long_runs.log) — and, since the one add per node, speed: the kernel is bound by the memory side's atomic units,
+// and a fused trip now costs 8 requests for 64 updates where two trips cost 16 (C3 80.0 -> 87.4 G updates/s, bubble
+// graphs 49.9 -> 53.6 and 52.0 -> 55.8: profiles/r02/fused_trip_one_add.log).  Returns false when the wave's quota filled
 // before the second colour: the caller leaves that colour to the next iteration as a generic trip.
 template <bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ bool fused_trip(const KArgs &a, TeamState &ts, const Trip &cur, const int lane,
@@ -174,6 +177,8 @@ __device__ __forceinline__ bool fused_trip(const KArgs &a, TeamState &ts, const 
     const double term_dist = fabs(rec_pos(cur.ra) - rec_pos(cur.rb));                  // sgd.rs:513
     const int crowd = crowd_shift<true>(a, cur.ra, cur.rb);
     const bool term_ok = term_dist != 0.0 && node != 0xFFFFFFFFu && pnode != 0xFFFFFFFFu;   // :514, :525-538
+    double acc = 0.0;
+    bool touched = false, second = true;
 #pragma unroll
     for (uint32_t colour = 0; colour < 2u; ++colour) {
         ++ts.att;
@@ -206,15 +211,16 @@ __device__ __forceinline__ bool fused_trip(const KArgs &a, TeamState &ts, const 
         // a lane acts or receives in a colour, never both (its group's parity decides)
         if (valid) xo = xo - r_x;                                                      // :575  x[i] - r_x
         if (recv) xo = xo + rv;                                                        // :576  x[j] + r_x
-        const bool o1f = valid || recv, o2f = valid && out;
-        const double o1v = valid ? -r_x : rv;
-        if (!(a.dbg & 1u)) {
-            if (o1f) add_pos(x + node, o1v);
-            if (o2f) add_pos(x + pnode, r_x);
-        }
-        if (colour == 0 && wave_done >= wave_quota) return false;
+        // a lane's own node takes ONE add for both colours, the sum of what it gave as an acting lane in one colour and
+        // took as a partner in the other (its register holds (x - r) + r', memory receives x + (-r + r')): half the
+        // atomic requests of the trip
+        if (valid) { acc = touched ? acc - r_x : -r_x; touched = true; }
+        if (recv) { acc = touched ? acc + rv : rv; touched = true; }
+        if (valid && out && !(a.dbg & 1u)) add_pos(x + pnode, r_x);                    // partner beyond the trip
+        if (colour == 0 && wave_done >= wave_quota) { second = false; break; }
     }
-    return true;
+    if (touched && !(a.dbg & 1u)) add_pos(x + node, acc);
+    return second;
 }
 
 // One SGD iteration of one wave: passes and trips until the wave's quota is filled.
@@ -349,8 +355,10 @@ __device__ __forceinline__ uint64_t wave_quota_of(const KArgs &a, uint32_t tid) 
     return wq;
 }
 
+// (5 waves per SIMD: 96 VGPRs and a few spilled registers instead of 123 — the kernel waits on memory 68 % of its
+// cycles, and a fifth wave per SIMD = 1 280 lanes per CU is worth +3 % on C3, 77.5 -> 80.0 G updates/s)
 template <int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
-__global__ void sgd1d_team_kernel(const KArgs a) {
+__global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) sgd1d_team_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
     stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
@@ -374,7 +382,7 @@ __global__ void sgd1d_team_kernel(const KArgs a) {
 // still (a 1 ms polling thread, sgd.rs:366-403) — but every iteration still applies exactly
 // min_term_updates updates with its own eta/theta.  Saves the per-launch ramp, tail and RNG round trip.
 template <int B, bool LDS_TABLES, bool ATOMIC_LOADS>
-__global__ void sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters) {
+__global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
     stage_tables<LDS_TABLES>(a0, smem, path_tab, zeta_tab);
@@ -479,19 +487,25 @@ hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_i
 
 // The first launch of a kernel function costs the host ~0.1 ms (the runtime materialises the function lazily); a
 // caller that brackets its launch with events pays that inside the bracket.  Resolve the fused kernel a context will
-// use when the context is set up instead.
+// use when the context is set up instead — and report how many of its workgroups one CU holds at once (registers,
+// waves per SIMD and the LDS table all count): the fused kernel has no grid barrier and must be launched with every
+// workgroup resident (capi.hip setup_common).
 template <int B>
-static hipError_t prepare_1d_fused_b(bool lds_tables) {
+static hipError_t prepare_1d_fused_b(bool lds_tables, int block, size_t lds, int *blocks_per_cu) {
     hipFuncAttributes attr;
-    if (lds_tables) return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&sgd1d_team_fused_kernel<B, true, true>));
-    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&sgd1d_team_fused_kernel<B, false, true>));
+    const void *fn = lds_tables ? reinterpret_cast<const void *>(&sgd1d_team_fused_kernel<B, true, true>)
+                                : reinterpret_cast<const void *>(&sgd1d_team_fused_kernel<B, false, true>);
+    hipError_t e = hipFuncGetAttributes(&attr, fn);
+    if (e != hipSuccess) return e;
+    return lds_tables ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, sgd1d_team_fused_kernel<B, true, true>, block, lds)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, sgd1d_team_fused_kernel<B, false, true>, block, 0);
 }
-hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables) {
+hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu) {
     switch (bundle) {
-        case 16: return prepare_1d_fused_b<16>(lds_tables);
-        case 32: return prepare_1d_fused_b<32>(lds_tables);
-        case 64: return prepare_1d_fused_b<64>(lds_tables);
-        default: return hipSuccess;
+        case 16: return prepare_1d_fused_b<16>(lds_tables, block, lds, blocks_per_cu);
+        case 32: return prepare_1d_fused_b<32>(lds_tables, block, lds, blocks_per_cu);
+        case 64: return prepare_1d_fused_b<64>(lds_tables, block, lds, blocks_per_cu);
+        default: *blocks_per_cu = 0; return hipSuccess;
     }
 }
 

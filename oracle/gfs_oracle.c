@@ -596,6 +596,7 @@ struct gfo_state {
     struct leader_s *lead; uint8_t *lead_left, *lead_cool, *lead_colour, *lead_seg;   /* 1D bundled mode: each wave's partly expanded pass */
     uint64_t chain;                                           /* longest run in trips (B = 64); mirror of GFS_F_CHAIN */
     int one_colour;                                           /* mirror of GFS_F_DBG_ONE_COLOUR */
+    int no_fused_trip;                                        /* mirror of GFS_F_DBG_NO_FUSED_TRIP */
     uint32_t *node_slot;                                     /* bundled mode: the product's internal node layout (line-aligned runs) */
     gfo_term *trace; uint64_t trace_per_stream;
     uint64_t total_upd, total_att, iterations;
@@ -698,6 +699,13 @@ int gfo_state_set_one_colour(gfo_state *s, int on) {
     return 0;
 }
 
+/* mirror of GFS_F_DBG_NO_FUSED_TRIP: the two colours of a short-jump trip as two trips (1D) */
+int gfo_state_set_no_fused_trip(gfo_state *s, int on) {
+    if (!s) return -1;
+    s->no_fused_trip = on ? 1 : 0;
+    return 0;
+}
+
 /* nD term with the two end flips already drawn (team mode): same arithmetic as term_nd. */
 static int nd_prepare(const pidx *pi, uint64_t sa, uint64_t sb, int fa, int fb,
                       double *term_dist, uint64_t *idx_i, uint64_t *idx_j) {
@@ -787,6 +795,83 @@ static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t
     return L;
 }
 
+/* Product: sgd_kernel_common.h merged_trip_shift — a short-jump trip (B = 64, 0 < |jump| < 64) whose 64 steps and all
+ * their partners lie inside the path without wrapping.  Returns the signed jump, or 0. */
+static int64_t merged_trip_shift(const leader_t *ld, uint64_t off) {
+    if (!ld->ok || ld->aligned || ld->cnt < 128) return 0;
+    const int64_t sh = (int64_t)ld->rb0 - (int64_t)ld->ra0;
+    if (sh == 0 || sh >= 64 || sh <= -64) return 0;
+    uint64_t base = ld->ra0 + off;
+    if (base >= ld->cnt) base -= ld->cnt;
+    if (base + 64 > ld->cnt) return 0;
+    if (sh > 0 ? base + 63 + (uint64_t)sh > ld->cnt - 1 : (int64_t)base + sh < 0) return 0;
+    return sh;
+}
+
+/* Product: sgd_kernels_1d.hip fused_trip — both colours of such a trip in one go, as the wave executes them: every lane
+ * holds the position of its own step's node in a register (and its partner's when the partner lies beyond the trip's 64
+ * steps), colour 1 computes on what colour 0 left in the registers, and a lane's node receives ONE add, the sum of its
+ * two contributions: x + (-r + r'), not (x - r) + r'.  Partners beyond the trip are added per colour.  Lane order here;
+ * the wave applies them concurrently.  Returns 0 when the wave's quota filled between the colours. */
+static int fused_trip_1d(gfo_state *s, const iter_state *it, const leader_t *ld, uint64_t off, int64_t sh,
+                         uint64_t wave_first, uint64_t wave_quota, uint64_t *wave_done, double *x) {
+    const pidx *pi = &s->pi;
+    const uint64_t z = (uint64_t)(sh < 0 ? -sh : sh);
+    uint64_t base = ld->ra0 + off;
+    if (base >= ld->cnt) base -= ld->cnt;
+    uint32_t node[64], pnode[64]; int out[64], term_ok[64], touched[64] = {0}; uint64_t grp[64];
+    double xo[64], xp[64], td[64], acc[64] = {0.0};
+    for (int l = 0; l < 64; l++) {
+        const uint64_t sa = ld->first + base + (uint64_t)l, sb = (uint64_t)((int64_t)sa + sh);
+        node[l] = pi->rec[sa].node; pnode[l] = pi->rec[sb].node;
+        out[l] = l + sh < 0 || l + sh > 63;
+        xo[l] = node[l] != GFO_NO_NODE ? x[node[l]] : 0.0;
+        xp[l] = out[l] && pnode[l] != GFO_NO_NODE ? x[pnode[l]] : 0.0;
+        td[l] = fabs((double)pi->rec[sa].pos - (double)pi->rec[sb].pos);               /* sgd.rs:513 */
+        term_ok[l] = td[l] != 0.0 && node[l] != GFO_NO_NODE && pnode[l] != GFO_NO_NODE; /* :514, :525-538 */
+        grp[l] = ((off + (uint64_t)l) / z) & 1;
+    }
+    int second = 1;
+    for (uint64_t colour = 0; colour < 2; colour++) {
+        int valid[64]; double r[64];
+        uint64_t nvalid = 0, rank = 0;
+        for (int l = 0; l < 64; l++) { valid[l] = term_ok[l] && grp[l] == colour; nvalid += (uint64_t)valid[l]; }
+        const uint64_t remaining = wave_quota - *wave_done;
+        for (int l = 0; l < 64; l++) {
+            s->att[wave_first + l]++;
+            if (valid[l] && rank++ >= remaining) valid[l] = 0;
+        }
+        *wave_done += nvalid < remaining ? nvalid : remaining;
+        for (int l = 0; l < 64; l++) {                                 /* every term of a colour reads the same snapshot */
+            r[l] = 0.0;
+            if (!valid[l]) continue;
+            const double xj = out[l] ? xp[l] : xo[l + sh];
+            const double mu = fmin(it->eta * (1.0 / td[l]), 1.0);                      /* :518-520 */
+            double dx = xo[l] - xj;                                                    /* :543 */
+            if (dx == 0.0) dx = 1e-9;                                                  /* :546-548 */
+            const double mag = fabs(dx);                                               /* :551 */
+            const double delta = mu * (mag - td[l]) / 2.0;                             /* :552 */
+            r[l] = (delta / mag) * dx;                                                 /* :570-571 */
+            const uint64_t tg = wave_first + (uint64_t)l;
+            s->done[tg]++;                                                             /* :579 */
+            if (s->trace && s->ntr[tg] < s->trace_per_stream) {
+                gfo_term *tr = &s->trace[tg * s->trace_per_stream + s->ntr[tg]++];
+                tr->i = node[l]; tr->j = pnode[l]; tr->d_ij = td[l];
+            }
+        }
+        for (int l = 0; l < 64; l++) {
+            const int src = l - (int)sh;
+            const int recv = src >= 0 && src <= 63 && valid[src];
+            if (valid[l]) { xo[l] = xo[l] - r[l]; acc[l] = touched[l] ? acc[l] - r[l] : -r[l]; touched[l] = 1; }   /* :575 */
+            if (recv) { xo[l] = xo[l] + r[src]; acc[l] = touched[l] ? acc[l] + r[src] : r[src]; touched[l] = 1; }  /* :576 */
+            if (valid[l] && out[l]) x[pnode[l]] = x[pnode[l]] + r[l];
+        }
+        if (colour == 0 && *wave_done >= wave_quota) { second = 0; break; }
+    }
+    for (int l = 0; l < 64; l++) if (touched[l]) x[node[l]] = x[node[l]] + acc[l];
+    return second;
+}
+
 /* Team semantics of the product (sgd1d_team_kernel): per wave of 64 streams, a PASS samples one
  * leader per stream; B TRIPS then expand the 64 leaders as 64/B runs of B lanes (trip t, run q
  * uses leader t*(64/B)+q).  Wave-level quota with a rank cut-off.  1D: the trips of a pass left over when
@@ -837,6 +922,17 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                 }
                 /* trips of this slot's run (B = 64: one leader per trip) */
                 const uint64_t ktrips = (RUNS == 1 && L[t].ok && L[t].cnt >= 2 * B) ? run_trips(s, L[t].cnt) : 1;
+                if (s->D == 0 && RUNS == 1 && colour == 0 && two && !s->no_fused_trip) {
+                    const uint64_t off0 = run_offset(s, L[t].cnt, ktrips, L[t].ra0, L[t].rb0, seg);
+                    const int64_t ms = merged_trip_shift(&L[t], off0);
+                    if (ms != 0) {                                      /* both colours in one trip (product: fused_trip) */
+                        if (!fused_trip_1d(s, &it, &L[t], off0, ms, wave_first, wave_quota, &wave_done, x))
+                            s->lead_colour[w] = 1;                      /* quota filled between the colours */
+                        else if (seg + 1 < ktrips) s->lead_seg[w] = (uint8_t)(seg + 1);
+                        else { s->lead_seg[w] = 0; s->lead_left[w]--; }
+                        continue;
+                    }
+                }
                 /* what comes next: this trip's second colour, else the run's next trip, else the next slot */
                 if (colour == 0 && two) s->lead_colour[w] = 1;
                 else if (seg + 1 < ktrips) { s->lead_colour[w] = 0; s->lead_seg[w] = (uint8_t)(seg + 1); }

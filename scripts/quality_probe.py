@@ -66,7 +66,7 @@ def study(name, g, variants, seeds=2, chain=False, iter_max=None):
                 print(f"  {v:22s} seed {sd} bundle {st.bundle:2d} k {st.run_trips:2d} streams {st.n_streams:6d} {rate:6.2f} G/s  "
                       f"inversions vs chain {Q.inversions_vs_chain(g.node_ids[order].astype(np.int64))}  stress {s:.3e}", flush=True)
                 continue
-            print(f"  {v:10s} seed {sd} bundle {st.bundle:2d} streams {st.n_streams:6d} {rate:6.2f} G/s  stress {s:.6f} (2M pairs: {s2m:.6f})  "
+            print(f"  {v:10s} seed {sd} bundle {st.bundle:2d} streams {st.n_streams:6d} launches {st.launches} {rate:6.2f} G/s  stress {s:.6f} (2M pairs: {s2m:.6f})  "
                   f"rmse {lq['rmse']:.3f} mae {lq['mae']:.3f}  tau_vs_first {tau:.6f}  ({time.time() - t0:.0f} s)", flush=True)
             print("      by octave: " + " ".join(f"{r:.4f}" for r in rms), flush=True)
     ctx.close()

@@ -943,23 +943,25 @@ def test_two_ranks_on_one_gpu_layout_2d():
 
 
 # ---- implementation = specification for the team kernel: one wave replays the oracle's sequential MIRROR bit for bit ----
-@pytest.mark.parametrize("fused", [False, True])
-def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(fused):
+@pytest.mark.parametrize("fused,fused_trip", [(False, True), (True, True), (True, False)])
+def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(fused, fused_trip):
     """Implementation = specification.  One wave of 64 streams, B = 64: trips run
     one after another and the adds of a trip go to distinct nodes on a graph whose paths visit no node twice, so
     the concurrent GPU trip equals the mirror's lane-by-lane application — positions must agree to the last bit.
-    Covers the arithmetic of the product's main kernel including line-aligned long runs, fused two-colour trips and merged
-    short-jump trips at path ends."""
+    Covers the arithmetic of the product's main kernel including line-aligned long runs, fused two-colour trips (a node
+    receives ONE add for both colours: x + (-r + r'), which rounds differently from (x - r) + r' — the mirror does the
+    same; fused_trip = False: the two colours as two trips, GFS_F_DBG_NO_FUSED_TRIP) and merged short-jump trips at path
+    ends.  fused: one launch for the whole schedule / one per iteration."""
     g = G.synth_windows(40_000, 8, 20_000, 12)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
     p.iter_max = 8
     p.min_term_updates = 200_000
     og, op = oracle_graph(g), oracle_params(p)
-    st_o = O.State(og, op, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64))
+    st_o = O.State(og, op, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64), fused_trip=fused_trip)
     x_ref = O.init_positions(og)
     st_o.run(x_ref)
     so = st_o.stats()
-    flags = hip.F_BUNDLE(64) | (0 if fused else hip.F_NO_FUSE)
+    flags = hip.F_BUNDLE(64) | (0 if fused else hip.F_NO_FUSE) | (0 if fused_trip else hip.F_DBG_NO_FUSED_TRIP)
     ctx = hip.Context(g)
     ctx.setup_1d(p, hip.make_config(n_streams=64, flags=flags))
     ctx.upload(hip.init_positions(g))

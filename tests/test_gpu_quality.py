@@ -57,9 +57,19 @@ def test_default_flags_on_a_525k_node_bubble_graph_against_the_cpu_oracle_and_re
     assert st.bundle == 64 and st.run_trips == 64 and st.launches == 1        # what the library picks by itself
     assert st.term_updates == (p.iter_max + 1) * p.min_term_updates
     x_b1, st1 = _run_default(ctx, p, hip.F_BUNDLE(1))
-    ctx.close()
     assert st1.bundle == 1 and st1.term_updates == st.term_updates
     _compare(g, og, x_b1, x_def, "default flags vs GPU reference streams")
+    # More streams than the chip holds at once (this graph's 33 KB zeta table in LDS = 4 workgroups of 256 per CU = 4096
+    # waves; 4101 asked for): the barrier-free fused launch would let the 5 late waves walk the whole schedule after the
+    # others are done (relative error 64 at path distance 1 when it did), so the library runs one launch per iteration.
+    before = ctx.stats().launches                               # (counted over the context's life)
+    ctx.setup_1d(p, hip.make_config(n_streams=262_464))
+    ctx.init_positions()
+    ctx.run()
+    x_many, stm = ctx.download(), ctx.stats()
+    ctx.close()
+    assert stm.n_streams == 262_464 and stm.bundle == 64 and stm.launches - before == p.iter_max + 1 and stm.term_updates == st.term_updates
+    _compare(g, og, x_b1, x_many, "more streams than resident workgroups vs GPU reference streams")
     # the CPU oracle, executed as the reference executes: worker threads + checker thread (flat arrays, all host cores)
     import os
     op = oracle_params(p)
