@@ -20,7 +20,8 @@ hipError_t launch_1d(const KArgs &a, bool lds_tables, bool atomic_loads, bool tr
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_loads, bool trace,
                      dim3 grid, dim3 block, size_t lds, hipStream_t st);
-hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
+size_t pool_bytes(uint64_t n_iters);
+hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
                            dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t warm_module_1d();
 hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu);
@@ -313,15 +314,17 @@ struct gfs_ctx {
     double *d_zetas = nullptr; uint64_t zlen_full = 0, zlen_staged = 0;
     double *d_x = nullptr; bool x_owned = false; uint64_t x_len = 0;
     uint64_t *d_rng = nullptr;
-    uint32_t *d_lead = nullptr;      // 1D team kernels: the waves' partly expanded passes, [6][n_streams]
+    uint32_t *d_lead = nullptr;      // 1D team kernels: the waves' partly expanded passes, [8][n_streams]
     unsigned long long *d_counters = nullptr;
     gfs_term *d_trace = nullptr; uint32_t *d_trace_cnt = nullptr;
     gfs::IterConsts *d_its = nullptr; uint64_t its_cap = 0;   // schedule slice of a fused launch (arbitrary lists)
     gfs::IterConsts *d_its_all = nullptr;                     // constants of iterations 0..=iter_max, resident
+    uint32_t *d_pool = nullptr; uint64_t pool_cap = 0;        // fused launch: per-iteration work pool counters (sgd_kernels_1d.hip)
     uint64_t n_streams = 0, quota_total = 0;
     uint64_t fused_resident_blocks = 0; // workgroups of the fused 1D kernel the chip holds at once (block size, LDS table)
     uint32_t block = 256;
     uint32_t bundle = 1;               // lanes per sampling bundle actually used (1 = reference streams)
+    uint32_t partners = 1;             // partner draws per leader (2: 1D team kernel at B = 64)
     uint32_t chain = 1;                // longest run in trips (sgd_device.h run_trips); 1 = a run is one trip
     bool lds_tables = true, atomic_loads = true;
     size_t lds_bytes = 0;
@@ -346,6 +349,8 @@ static void free_sgd_state(gfs_ctx *c) {
     if (c->d_its) (void)hipFree(c->d_its);
     if (c->d_its_all) (void)hipFree(c->d_its_all);
     c->d_its = nullptr; c->its_cap = 0; c->d_its_all = nullptr;
+    if (c->d_pool) (void)hipFree(c->d_pool);
+    c->d_pool = nullptr; c->pool_cap = 0;
     c->d_zetas = nullptr; c->d_x = nullptr; c->d_rng = nullptr; c->d_counters = nullptr;
     c->d_trace = nullptr; c->d_trace_cnt = nullptr; c->x_owned = false; c->configured = false;
 }
@@ -404,7 +409,7 @@ static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
     // 5 % from 512 up.  (976 rather than 1024 keeps 4*streams <= 1e6 nodes, the deferral condition, on C3-sized graphs.)
     // Round 2: the 1D team kernels are built for 5 waves per SIMD and get 1 280 lanes per CU (327 680 on MI355X): C3 77.5 G
     // updates/s at 249 856 streams, 78.0 at 294 912, 80.0 at 327 680 (profiles/r02/streams_5_waves.log).
-    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1280 : 976);
+    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1024 : 976);
     // keep >= 8 updates per stream per batch on small graphs
     const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
     // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight
@@ -456,6 +461,8 @@ static int choose_bundle(gfs_ctx *c, int dims) {
     // profile of the 2-D layout is already below reference streams' at 16: profiles/r02/quality_probe_layout_k.log)
     if (k == 0) k = dims ? 16 : 64;
     c->chain = b == 64 ? k : 1;                       // (nD: team kernels exist for D <= 3; checked above)
+    // Two partners per leader (sgd_device.h Leader): the 1D team kernel at B = 64, unless GFS_F_ONE_PARTNER
+    c->partners = (b == 64 && dims == 0 && !(c->cfg.flags & GFS_F_ONE_PARTNER)) ? 2u : 1u;
     return GFS_OK;
 }
 
@@ -525,8 +532,8 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
 
     HIPCHK(hipMalloc(&c->d_rng, 4 * T * 8));
     if (dims == 0 && c->bundle > 1) {
-        HIPCHK(hipMalloc(&c->d_lead, 6 * T * sizeof(uint32_t)));
-        HIPCHK(hipMemset(c->d_lead, 0, 6 * T * sizeof(uint32_t)));      // trips left = 0: no pass yet
+        HIPCHK(hipMalloc(&c->d_lead, 8 * T * sizeof(uint32_t)));
+        HIPCHK(hipMemset(c->d_lead, 0, 8 * T * sizeof(uint32_t)));      // trips left = 0: no pass yet
     }
     HIPCHK(hipMalloc(&c->d_counters, kCounterBytes));
     if (c->cfg.trace_per_stream) {
@@ -778,7 +785,7 @@ int gfs_ctx_reset_streams(gfs_ctx *c) {
     if (!c || !c->d_rng) return fail(GFS_E_STATE, "context not set up");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    if (c->d_lead) HIPCHK(hipMemset(c->d_lead, 0, 6 * c->n_streams * sizeof(uint32_t)));
+    if (c->d_lead) HIPCHK(hipMemset(c->d_lead, 0, 8 * c->n_streams * sizeof(uint32_t)));
     return seed_streams(c);
 }
 
@@ -801,9 +808,10 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.space_max = (uint32_t)std::min<uint64_t>(c->params.space_max, 0xFFFFFFFFull);
     a.space_q = (uint32_t)std::min<uint64_t>(c->params.space_quantization_step, 0xFFFFFFFFull);
     a.dbg = (c->cfg.flags >> 8) & 0x7Fu;             // bit 0x40 = GFS_F_DBG_WIDE_INDEX >> 8
-    if (c->cfg.flags & GFS_F_DBG_NO_FUSED_TRIP) a.dbg |= 0x100u;
+    if (c->cfg.flags & GFS_F_DBG_NO_FUSED_TRIP) a.dbg |= 0x100u;     // (GFS_F_DBG_NO_TWIN_TRIP 0x400 arrives as dbg bit 0x04)
     a.bundle = c->bundle;
     a.chain = c->chain;
+    a.partners = c->partners;
     a.n_nodes = (uint32_t)c->n_nodes;
     {   // crowding onset (sgd_device.h crowd_shift): four times the concurrency of an average node
         const uint64_t per = c->n_steps / std::max<uint64_t>(2 * c->n_streams, 1);
@@ -899,7 +907,21 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     int rc = next_event_pair(c, ev);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev->first, st));
-    hipError_t e = gfs::launch_1d_fused(a, d_slice, (uint32_t)n, c->lds_tables, grid, block, c->lds_bytes, st);
+    // work pools (sgd_kernels_1d.hip): the waves draw an iteration's updates from shared counters, zeroed per launch.
+    // (A share per counter beyond 2^31 — 3e10 updates per iteration — keeps the fixed quotas.)
+    uint32_t *pool = nullptr;
+    const uint64_t n_waves = c->n_streams / 64;
+    if (!(c->cfg.flags & GFS_F_DBG_FREE_RUNNING) && c->quota_total / std::min<uint64_t>(16, std::max<uint64_t>(n_waves, 1)) < (1ull << 31)) {
+        if (c->pool_cap < n) {
+            if (c->d_pool) HIPCHK(hipFree(c->d_pool));
+            c->d_pool = nullptr; c->pool_cap = 0;
+            HIPCHK(hipMalloc(&c->d_pool, gfs::pool_bytes(n)));
+            c->pool_cap = n;
+        }
+        HIPCHK(hipMemsetAsync(c->d_pool, 0, gfs::pool_bytes(n), st));
+        pool = c->d_pool;
+    }
+    hipError_t e = gfs::launch_1d_fused(a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st);
     if (e != hipSuccess) return fail(GFS_E_HIP, std::string("fused kernel launch: ") + hipGetErrorString(e));
     HIPCHK(hipEventRecord(ev->second, st));
     c->iterations += n;

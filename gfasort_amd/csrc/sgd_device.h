@@ -95,8 +95,8 @@ struct KArgs {
     unsigned long long *counters;  // [slots][8]: [s][0] successful updates, [s][1] attempts (sgd_kernel_common.h)
     void           *trace;         // gfs_term[n_streams*trace_per_stream] or null
     uint32_t       *trace_cnt;     // [n_streams]
-    uint32_t       *lead;          // [6][n_streams] SoA: leaders a 1D team wave has sampled but not yet expanded
-                                   // (first lo, first hi, cnt, ra0, rb0, ok | trips left << 8 | cooling << 16); or null
+    uint32_t       *lead;          // [8][n_streams] SoA: leaders a 1D team wave has sampled but not yet expanded
+                                   // (first lo, first hi, cnt, ra0, rb0, ok | trips left << 8 | ..., ra1, rb1: load_pass); or null
     uint64_t n_steps, steps_thresh;   // thresh = (2^w - n) mod n, w = 32 if n_steps <= u32::MAX else 64
     uint32_t n_paths, zlen_full;   // zlen_full: true table length (index clamp, sgd.rs:469)
     uint32_t zlen_staged;          // entries copied to LDS (>= every reachable index)
@@ -108,6 +108,8 @@ struct KArgs {
     uint32_t bundle, n_nodes;      // lanes per sampling bundle (1 = reference streams); node count (nD planes)
     int32_t  kshift;               // crowding: floor(log2(n_steps / (2 * n_streams))) + 2, see crowd_shift()
     uint32_t chain;                // longest run in trips (power of two; 1 = a run is one trip), see run_trips()
+    uint32_t partners;             // partner draws per leader (1 or 2; 2 only for the 1D team kernel at B = 64), see Leader
+    uint32_t _pad4;
     IterConsts it;
 };
 
@@ -239,12 +241,27 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
 // a run coalesce into a few 64-B requests instead of B scattered ones — and since a pass fixes
 // the next B trips in advance, their record loads can be issued a trip ahead.
 // ------------------------------------------------------------------------------------------
-struct Leader {            // one sampled leader term (per lane, registers)
+struct Leader {            // one sampled leader (per lane, registers)
     uint32_t first_lo, first_hi, cnt;   // PathInfo of its path (first_step is 64-bit)
-    uint32_t ra0, rb0;     // ranks of step a and step b
+    uint32_t ra0, rb0;     // ranks of step a and step b (first partner)
     uint32_t ok;           // bit 0: 0 = the reference `continue`d (cnt == 1 or rank_a == rank_b);
-                           // bit 1: both runs line-aligned, bits 2..4: lane rotation r (sample_leader)
+                           // bit 1: both runs line-aligned, bits 2..4: lane rotation r (draw_partner);
+                           // bits 8..12: the same for the second partner
+    uint32_t ra1, rb1;     // TWO PARTNERS (KArgs.partners = 2): the same step a with a second, independent draw of step b
 };
+__device__ __forceinline__ uint32_t leader_ok(uint32_t okw, uint32_t p) { return (p ? okw >> 8 : okw) & 0x1Fu; }
+
+// TWO PARTNERS.  With KArgs.partners = 2 a leader is one draw of step a (sgd.rs:444-453) and TWO independent draws of its
+// partner b (sgd.rs:456-497), each from the reference's distribution given a: two terms that share their a-side.  Every
+// term keeps the reference's marginal distribution; once more only the correlation between terms changes (an a-run now
+// takes two corrections in a row, from two unrelated places of its path).  What it buys: when both partners are
+// line-aligned long jumps — most leaders on long paths — the two runs have the SAME a-side blocks, and a trip computes
+// both terms of a lane from one load of its a-side record and position, with one add for the a-side (TWIN trip,
+// sgd_kernels_1d.hip twin_trip): 3 blocks of records, position loads and atomic requests for 128 updates instead of 4.
+// The kernel is bound by the memory side's atomic units, then by HBM bytes; this takes a quarter off both.
+// A team wave works through an iteration in CHUNKS of this many updates (sgd_kernels_1d.hip, work pools); the rank cut-off
+// that makes a count exact applies at the end of every chunk.  2048 = 32 full trips.
+constexpr uint32_t TEAM_CHUNK = 2048;
 
 // LONG RUNS.  A leader is expanded not over one trip but over K consecutive trips of its wave: trip `seg` takes the
 // steps seg*B .. seg*B+B-1 further along the path, all with the leader's jump, so a run is K*B consecutive steps.
@@ -275,33 +292,28 @@ __device__ __forceinline__ uint32_t run_offset(uint32_t bundle, uint32_t cnt, ui
     return seg * (z < bundle ? cnt / k : bundle);
 }
 
-template <bool LDS_TABLES>
-__device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng) {
-    Leader L;
-    const uint64_t s0 = sample_step(a, rng);                                           // sgd.rs:444
-    const uint4 r0 = a.step_rec[s0];
-    const uint4 pr = path_tab[rec_path(r0)];                                           // :445-446
-    L.first_lo = pr.x; L.first_hi = pr.w; L.cnt = pr.y;
-    L.ra0 = (uint32_t)(s0 - path_first(pr)); L.rb0 = L.ra0;                            // :452-453
-    L.ok = 0;
-    if (L.cnt == 1u) return L;                                                         // :448
+// One draw of the partner of step a0 (rank in its path) — sgd.rs:456-497 — and the line alignment of the two runs.
+// ra = a0 on entry; on return the first steps of the a-run and of the b-run, and the partner's ok bits (Leader.ok).
+__device__ __forceinline__ uint32_t draw_partner(const KArgs &a, const double *zeta_tab, Rng &rng, const uint32_t cnt,
+                                                 const uint32_t thresh, const uint32_t slot0, uint32_t &ra, uint32_t &rb) {
+    rb = ra;
     if (a.it.cooling || rng.flip() == 1u) {                                            // :456
         bool back = false, fwd = false;
-        if (L.ra0 > 0u && (rng.flip() == 1u || L.ra0 == L.cnt - 1u)) back = true;      // :460
-        else if (L.ra0 < L.cnt - 1u) fwd = true;                                       // :475
+        if (ra > 0u && (rng.flip() == 1u || ra == cnt - 1u)) back = true;              // :460
+        else if (ra < cnt - 1u) fwd = true;                                            // :475
         if (back || fwd) {
-            uint32_t room = back ? L.ra0 : (L.cnt - L.ra0 - 1u);
+            uint32_t room = back ? ra : (cnt - ra - 1u);
             uint32_t jump = a.space < room ? a.space : room;                           // :462,477
             double zeta = zeta_tab[space_index(a, jump)];
             uint32_t z = dirty_zipf(a.it, jump, zeta, rng.f64());                      // :472-473
-            if (back) L.rb0 = L.ra0 >= z ? L.ra0 - z : 0u;                             // :474
-            else { uint64_t t = (uint64_t)L.ra0 + z; L.rb0 = t < L.cnt - 1u ? (uint32_t)t : L.cnt - 1u; }  // :489
+            if (back) rb = ra >= z ? ra - z : 0u;                                      // :474
+            else { uint64_t t = (uint64_t)ra + z; rb = t < cnt - 1u ? (uint32_t)t : cnt - 1u; }  // :489
         }
     } else {
-        L.rb0 = rng.uniform32(L.cnt, pr.z);                                            // :493-494
+        rb = rng.uniform32(cnt, thresh);                                               // :493-494
     }
-    L.ok = (L.rb0 != L.ra0) ? 1u : 0u;                                                 // :497
-    if (L.ok && L.cnt >= 2u * a.bundle && r0.x != 0xFFFFFFFFu && !(a.dbg & 0x10u)) {        // only where a run will be expanded
+    uint32_t ok = (rb != ra) ? 1u : 0u;                                                // :497
+    if (ok && cnt >= 2u * a.bundle && slot0 != 0xFFFFFFFFu && !(a.dbg & 0x10u)) {        // only where a run will be expanded
         // Line-aligned runs, for jumps well beyond the run length.  Along a path laid out in slot order, a run that
         // starts on a multiple of 8 slots covers 8 lines of the position vector instead of 8.9.
         //  * The run starts sh = (slot of the leader's node) mod 8 steps before the leader (the leader's own term
@@ -315,21 +327,37 @@ __device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *pat
         //    jumps shorter than B + 8 are left alone altogether (there only some lanes act — node-disjoint rule — and
         //    a fixed phase would leave some neighbour pairs never sampled).
         // C3: 0.30 -> 0.26 atomic requests per update, 68 -> 74 G updates/s.
-        const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0;
+        const int64_t jump = (int64_t)rb - (int64_t)ra;
         const int64_t Bn = (int64_t)a.bundle;
-        const int64_t Rn = Bn * (int64_t)run_trips(a.chain, a.bundle, L.cnt);         // steps of the whole run (|jump| >= B + 8: contiguous)
+        const int64_t Rn = Bn * (int64_t)run_trips(a.chain, a.bundle, cnt);           // steps of the whole run (|jump| >= B + 8: contiguous)
         if (jump >= Bn + 8 || jump <= -(Bn + 8)) {
             const int64_t A = a.bundle < 8u ? (int64_t)a.bundle : 8;               // runs shorter than a line: align to the run length
-            const uint32_t sh = r0.x & (uint32_t)(A - 1);
-            if (L.ra0 >= sh) {
-                const int64_t na = (int64_t)L.ra0 - (int64_t)sh;
+            const uint32_t sh = slot0 & (uint32_t)(A - 1);
+            if (ra >= sh) {
+                const int64_t na = (int64_t)ra - (int64_t)sh;
                 const int64_t r = ((jump % A) + A) % A, zp = jump - r, nb = na + zp;
-                if (!(a.dbg & 0x20u) && na + Rn <= (int64_t)L.cnt && nb >= 0 && nb + Rn <= (int64_t)L.cnt && (zp >= Bn || zp <= -Bn)) {
-                    L.ra0 = (uint32_t)na; L.rb0 = (uint32_t)nb; L.ok = 1u | 2u | ((uint32_t)r << 2);
-                } else if (L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
+                if (!(a.dbg & 0x20u) && na + Rn <= (int64_t)cnt && nb >= 0 && nb + Rn <= (int64_t)cnt && (zp >= Bn || zp <= -Bn)) {
+                    ra = (uint32_t)na; rb = (uint32_t)nb; ok = 1u | 2u | ((uint32_t)r << 2);
+                } else if (rb >= sh) { ra -= sh; rb -= sh; }
             }
         }
     }
+    return ok;
+}
+
+template <bool LDS_TABLES>
+__device__ __forceinline__ Leader sample_leader(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng) {
+    Leader L;
+    const uint64_t s0 = sample_step(a, rng);                                           // sgd.rs:444
+    const uint4 r0 = a.step_rec[s0];
+    const uint4 pr = path_tab[rec_path(r0)];                                           // :445-446
+    L.first_lo = pr.x; L.first_hi = pr.w; L.cnt = pr.y;
+    L.ra0 = (uint32_t)(s0 - path_first(pr)); L.rb0 = L.ra0;                            // :452-453
+    L.ra1 = L.ra0; L.rb1 = L.ra0;
+    L.ok = 0;
+    if (L.cnt == 1u) return L;                                                         // :448
+    L.ok = draw_partner(a, zeta_tab, rng, L.cnt, pr.z, r0.x, L.ra0, L.rb0);
+    if (a.partners == 2u) L.ok |= draw_partner(a, zeta_tab, rng, L.cnt, pr.z, r0.x, L.ra1, L.rb1) << 8;
     return L;
 }
 

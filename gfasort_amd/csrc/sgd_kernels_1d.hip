@@ -85,15 +85,18 @@ struct TeamState {
     // (`colour` = 1: the current slot's first colour is done, its second is next — sgd_device.h two_colour).
     // A pass outlives the iteration it was sampled in (eta is not part of sampling); it is dropped when
     // the cooling phase — the only thing the sampler depends on besides the RNG — changes.
-    Leader L = {0, 0, 0, 0, 0, 0};
+    Leader L = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t left = 0, cool = 0, colour = 0, seg = 0;   // seg: next trip of the current slot's run (sgd_device.h run_trips)
+    uint32_t p = 0;                                     // partner of the current slot's leader the next trip belongs to
     uint32_t done = 0, att = 0, ntr = 0;
 };
 
-// One trip = (slot t of the pass, trip seg of its run, colour): what every lane needs to execute it.
+// One trip = (slot t of the pass, trip seg of its run, partner, colour): what every lane needs to execute it.
 struct Trip {
     uint64_t sa = 0, sb = 0;
     uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+    uint4 rc = make_uint4(0, 0, 0, 0);   // twin trip: the record of the second partner's step
+    bool twin = false;         // wave-uniform: both partners of an aligned leader in ONE trip (twin_trip)
     bool valid = false;        // this lane acts in the trip (fused trip: this lane's partner lies beyond the trip's 64 steps)
     int mshift = 0;            // != 0: merged short-jump trip (sgd_kernel_common.h merged_trip_shift)
     bool two = false;          // wave-uniform: some run of this slot has a second colour
@@ -103,19 +106,40 @@ struct Trip {
 };
 
 template <int B>
-__device__ __forceinline__ void expand_trip(const KArgs &a, const Leader &L, int t, uint32_t seg, uint32_t colour, int sub, int q, Trip &tr) {
+__device__ __forceinline__ void expand_trip(const KArgs &a, const Leader &L, int t, uint32_t seg, uint32_t p, uint32_t colour, int sub, int q, Trip &tr) {
     constexpr int RUNS = 64 / B;
     const int ll = t * RUNS + q;
-    const uint32_t ok = bcast<B>(L.ok, ll), cnt = bcast<B>(L.cnt, ll), ra0 = bcast<B>(L.ra0, ll), rb0 = bcast<B>(L.rb0, ll);
+    const uint32_t okw = bcast<B>(L.ok, ll), cnt = bcast<B>(L.cnt, ll);
+    const uint32_t ok = leader_ok(okw, p);
+    const uint32_t ra0 = p ? bcast<B>(L.ra1, ll) : bcast<B>(L.ra0, ll), rb0 = p ? bcast<B>(L.rb1, ll) : bcast<B>(L.rb0, ll);
     const uint64_t first = bcast_first<B>(L, ll);
-    // long runs only where the whole wave follows one leader; a leader the reference rejected takes one (empty) trip
-    tr.k = (B == 64 && (ok & 1u) && cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, cnt) : 1u;
+    // long runs only where the whole wave follows one leader; a leader the reference rejected takes one (empty) trip.
+    // (The number of trips must not depend on the partner: the trips of a slot go seg by seg, both partners each.)
+    tr.k = (B == 64 && ((okw | (okw >> 8)) & 1u) && cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, cnt) : 1u;
     tr.off = B == 64 ? run_offset((uint32_t)B, cnt, tr.k, ra0, rb0, seg) : 0u;
     tr.mshift = merged_trip_shift<B>(ok, cnt, ra0, rb0, tr.off);
     const bool two = !(a.dbg & 0x08u) && two_colour<B>(ok, cnt, ra0, rb0);
     tr.two = B == 64 ? two : (__any(two) != 0);                       // B = 64: the leader is wave-uniform already
-    tr.ra = make_uint4(0, 0, 0, 0); tr.rb = make_uint4(0, 0, 0, 0);
+    tr.ra = make_uint4(0, 0, 0, 0); tr.rb = make_uint4(0, 0, 0, 0); tr.rc = make_uint4(0, 0, 0, 0);
     tr.fused = B == 64 && tr.mshift != 0 && colour == 0 && two && !(a.dbg & 0x100u);
+    // both partners line-aligned long jumps: their a-runs are the same blocks (draw_partner), one trip serves both
+    tr.twin = B == 64 && p == 0u && a.partners == 2u && (okw & 3u) == 3u && ((okw >> 8) & 3u) == 3u && !(a.dbg & 0x04u);
+    const uint32_t rb1 = bcast<B>(L.rb1, ll);
+    if (tr.twin) {
+        // ... unless the two partner runs overlap or touch: the wave would read, as one partner's positions, what it has only
+        // just added as the other's (no-return atomics are posted).  With such leaders as twin trips the 525k-node bubble
+        // graph lost a quarter of its precision at path distance 1 (profiles/r02/two_partners.log).
+        const int64_t gap = (int64_t)rb0 - (int64_t)rb1, lim = (int64_t)tr.k * 64 + 64;
+        if (gap < lim && gap > -lim) tr.twin = false;
+    }
+    if (tr.twin) {
+        tr.sa = first + ra0 + tr.off + (uint32_t)sub;
+        tr.sb = first + rb0 + tr.off + (((uint32_t)sub + ((okw >> 2) & 7u)) & 63u);
+        const uint64_t sc = first + rb1 + tr.off + (((uint32_t)sub + ((okw >> 10) & 7u)) & 63u);
+        tr.valid = true;
+        tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb]; tr.rc = a.step_rec[sc];
+        return;
+    }
     if (tr.fused) {
         // every lane takes its own step of the trip and its partner's record (the partners inside the trip are the other
         // lanes' own steps: the same lines, no extra traffic; merged_trip_shift guarantees all of them lie in the path)
@@ -223,6 +247,57 @@ __device__ __forceinline__ bool fused_trip(const KArgs &a, TeamState &ts, const 
     return second;
 }
 
+// TWIN trip (B = 64, two partners, both line-aligned long jumps: sgd_device.h Leader).  A lane's step a is the a-side of two
+// terms, (a, b) and (a, c), b and c in two other aligned blocks of the path.  One load of a's record and position serves
+// both; the second term computes on what the first left in the register, as it would read it back from memory; a's node
+// takes ONE add, -(r + r'), b and c one each: 3 blocks of 8 requests for 128 updates where two trips take 4.  Returns false
+// when the wave's quota filled before the second term: the caller leaves the second partner's trip to the next iteration.
+template <bool ATOMIC_LOADS, bool TRACE>
+__device__ __forceinline__ bool twin_trip(const KArgs &a, TeamState &ts, const Trip &cur, const int lane,
+                                          const uint32_t tid, const uint64_t wave_quota, uint64_t &wave_done) {
+    double *x = a.x;
+    const uint32_t node = cur.ra.x, nb = cur.rb.x, nc = cur.rc.x;
+    double xa = 0.0, xb = 0.0, xc = 0.0;
+    if (!(a.dbg & 2u)) {
+        if (node != 0xFFFFFFFFu) xa = load_pos<ATOMIC_LOADS>(x + node);
+        if (nb != 0xFFFFFFFFu) xb = load_pos<ATOMIC_LOADS>(x + nb);
+        if (nc != 0xFFFFFFFFu) xc = load_pos<ATOMIC_LOADS>(x + nc);
+    } else { xa = (double)node; xb = (double)nb; xc = (double)nc; }
+    const double pa = rec_pos(cur.ra);
+    double acc = 0.0;
+    bool touched = false, second = true;
+#pragma unroll
+    for (uint32_t p = 0; p < 2u; ++p) {
+        ++ts.att;
+        const uint4 &rp = p ? cur.rc : cur.rb;
+        const uint32_t pn = p ? nc : nb;
+        const double term_dist = fabs(pa - rec_pos(rp));                               // sgd.rs:513
+        bool valid = term_dist != 0.0 && node != 0xFFFFFFFFu && pn != 0xFFFFFFFFu;     // :514, :525-538
+        const unsigned long long vmask = __ballot(valid);
+        const uint64_t remaining = wave_quota - wave_done;
+        const uint32_t nvalid = (uint32_t)__popcll(vmask);
+        if (valid && nvalid > remaining) valid = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull)) < remaining;
+        wave_done += nvalid < remaining ? nvalid : remaining;
+        if (valid) {
+            const double r_x = term_move(a, term_dist, xa, p ? xc : xb, crowd_shift<true>(a, cur.ra, rp));   // :518-571
+            ++ts.done;                                                                 // :579
+            if (TRACE) {
+                if (ts.ntr < a.trace_per_stream) {
+                    TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ts.ntr;
+                    tt->i = node; tt->j = pn; tt->d = term_dist;
+                    ++ts.ntr;
+                }
+            }
+            xa = xa - r_x;                                                             // :575
+            acc = touched ? acc - r_x : -r_x; touched = true;
+            if (!(a.dbg & 1u)) add_pos(x + pn, r_x);                                   // :576
+        }
+        if (p == 0u && wave_done >= wave_quota) { second = false; break; }
+    }
+    if (touched && !(a.dbg & 1u)) add_pos(x + node, acc);
+    return second;
+}
+
 // One SGD iteration of one wave: passes and trips until the wave's quota is filled.
 template <int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
@@ -237,37 +312,50 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
         if (ts.left == 0 || ts.cool != (uint32_t)a.it.cooling) {
             ++passes;
             ts.L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, ts.rng);
-            ts.left = B; ts.cool = (uint32_t)a.it.cooling; ts.colour = 0; ts.seg = 0;
+            ts.left = B; ts.cool = (uint32_t)a.it.cooling; ts.colour = 0; ts.seg = 0; ts.p = 0;
         }
         const Leader &L = ts.L;
         int t = B - (int)ts.left;
-        uint32_t colour = ts.colour, seg = ts.seg;
+        uint32_t colour = ts.colour, seg = ts.seg, p = ts.p;
         Trip cur;
-        expand_trip<B>(a, L, t, seg, colour, sub, q, cur);             // expand and request the records of the first trip
+        expand_trip<B>(a, L, t, seg, p, colour, sub, q, cur);          // expand and request the records of the first trip
         for (;;) {
-            // the trip after this one: this trip's second colour (unless fused into it), else the run's next trip, else the
-            // next slot; request its records now
-            int t_n = t; uint32_t colour_n = 0u, seg_n = seg;
+            // the trip after this one: this trip's second colour (unless fused into it), else the same trip of the run for
+            // the leader's second partner (unless this is a twin trip), else the run's next trip, else the next slot;
+            // request its records now
+            int t_n = t; uint32_t colour_n = 0u, seg_n = seg, p_n = p;
             if (colour == 0 && cur.two && !cur.fused) colour_n = 1u;
-            else if (seg + 1u < cur.k) seg_n = seg + 1u;
-            else { t_n = t + 1; seg_n = 0u; }
+            else if (p == 0u && a.partners == 2u && !cur.twin) p_n = 1u;
+            else if (seg + 1u < cur.k) { seg_n = seg + 1u; p_n = 0u; }
+            else { t_n = t + 1; seg_n = 0u; p_n = 0u; }
             const bool have_n = t_n < B;
             Trip nxt;
-            if (have_n) expand_trip<B>(a, L, t_n, seg_n, colour_n, sub, q, nxt);
-            if (B == 64 && cur.fused) {
-                if (!fused_trip<ATOMIC_LOADS, TRACE>(a, ts, cur, lane, tid, wave_quota, wave_done)) {
-                    ts.colour = 1u; ts.seg = seg;                      // quota filled between the colours: the second one is
-                    break;                                             // the next iteration's first trip (generic form)
+            if (have_n) expand_trip<B>(a, L, t_n, seg_n, p_n, colour_n, sub, q, nxt);
+            if (B == 64 && cur.twin) {
+                if (!twin_trip<ATOMIC_LOADS, TRACE>(a, ts, cur, lane, tid, wave_quota, wave_done)) {
+                    ts.colour = 0u; ts.seg = seg; ts.p = 1u;           // quota filled between the partners: the second one
+                    break;                                             // is the next iteration's first trip (generic form)
                 }
-                ts.colour = 0u; ts.seg = seg_n;
+                ts.colour = 0u; ts.seg = seg_n; ts.p = 0u;
                 if (t_n != t) --ts.left;
                 if (wave_done >= wave_quota || !have_n) break;
-                cur = nxt; t = t_n; colour = colour_n; seg = seg_n;
+                cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
+                continue;
+            }
+            if (B == 64 && cur.fused) {
+                if (!fused_trip<ATOMIC_LOADS, TRACE>(a, ts, cur, lane, tid, wave_quota, wave_done)) {
+                    ts.colour = 1u; ts.seg = seg; ts.p = p;            // quota filled between the colours: the second one is
+                    break;                                             // the next iteration's first trip (generic form)
+                }
+                ts.colour = 0u; ts.seg = seg_n; ts.p = p_n;
+                if (t_n != t) --ts.left;
+                if (wave_done >= wave_quota || !have_n) break;
+                cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
                 continue;
             }
             // consume the current trip
             ++ts.att;
-            ts.colour = colour_n; ts.seg = seg_n;
+            ts.colour = colour_n; ts.seg = seg_n; ts.p = p_n;
             if (t_n != t) --ts.left;
             bool valid = cur.valid;
             const uint4 ra = cur.ra, rb = cur.rb;
@@ -326,25 +414,31 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
             }
             if (wave_done >= wave_quota) break;                                        // what is left of the pass serves the next iteration
             if (!have_n) break;
-            cur = nxt; t = t_n; colour = colour_n; seg = seg_n;
+            cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
         }
     }
 }
 
+// lead word: ok bits of partner 0 (0..7) | trips left (8..15) | cooling (16) | colour (17) | seg (18..25) | partner (26) |
+// ok bits of partner 1 (27..31)
 __device__ __forceinline__ void load_pass(const KArgs &a, uint32_t tid, TeamState &ts) {
     if (!a.lead) return;
     const uint64_t T = a.n_streams;
     ts.L.first_lo = a.lead[tid]; ts.L.first_hi = a.lead[T + tid]; ts.L.cnt = a.lead[2 * T + tid];
     ts.L.ra0 = a.lead[3 * T + tid]; ts.L.rb0 = a.lead[4 * T + tid];
     const uint32_t w = a.lead[5 * T + tid];
-    ts.L.ok = w & 0xFFu; ts.left = (w >> 8) & 0xFFu; ts.cool = (w >> 16) & 1u; ts.colour = (w >> 17) & 1u; ts.seg = (w >> 18) & 0xFFu;
+    ts.L.ra1 = a.lead[6 * T + tid]; ts.L.rb1 = a.lead[7 * T + tid];
+    ts.L.ok = (w & 0xFFu) | ((w >> 27) << 8);
+    ts.left = (w >> 8) & 0xFFu; ts.cool = (w >> 16) & 1u; ts.colour = (w >> 17) & 1u; ts.seg = (w >> 18) & 0xFFu; ts.p = (w >> 26) & 1u;
 }
 __device__ __forceinline__ void store_pass(const KArgs &a, uint32_t tid, const TeamState &ts) {
     if (!a.lead) return;
     const uint64_t T = a.n_streams;
     a.lead[tid] = ts.L.first_lo; a.lead[T + tid] = ts.L.first_hi; a.lead[2 * T + tid] = ts.L.cnt;
     a.lead[3 * T + tid] = ts.L.ra0; a.lead[4 * T + tid] = ts.L.rb0;
-    a.lead[5 * T + tid] = (ts.L.ok & 0xFFu) | (ts.left << 8) | (ts.cool << 16) | (ts.colour << 17) | (ts.seg << 18);
+    a.lead[5 * T + tid] = (ts.L.ok & 0xFFu) | (ts.left << 8) | (ts.cool << 16) | (ts.colour << 17) | (ts.seg << 18) | (ts.p << 26) |
+                          (((ts.L.ok >> 8) & 0x1Fu) << 27);
+    a.lead[6 * T + tid] = ts.L.ra1; a.lead[7 * T + tid] = ts.L.rb1;
 }
 
 __device__ __forceinline__ uint64_t wave_quota_of(const KArgs &a, uint32_t tid) {
@@ -358,7 +452,7 @@ __device__ __forceinline__ uint64_t wave_quota_of(const KArgs &a, uint32_t tid) 
 // (5 waves per SIMD: 96 VGPRs and a few spilled registers instead of 123 — the kernel waits on memory 68 % of its
 // cycles, and a fifth wave per SIMD = 1 280 lanes per CU is worth +3 % on C3, 77.5 -> 80.0 G updates/s)
 template <int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
-__global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) sgd1d_team_kernel(const KArgs a) {
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
     stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
@@ -369,20 +463,38 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) sgd1d_team_kernel(con
     ts.rng.s0 = a.rng[tid]; ts.rng.s1 = a.rng[T + tid]; ts.rng.s2 = a.rng[2 * T + tid]; ts.rng.s3 = a.rng[3 * T + tid];
     ts.ntr = TRACE ? a.trace_cnt[tid] : 0;
     load_pass(a, tid, ts);
-    team_iteration<B, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wave_quota_of(a, tid));
+    const uint64_t wq = wave_quota_of(a, tid);                        // worked through in chunks, like a pool (K1c)
+    for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
+        team_iteration<B, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK);
     a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;
     if (TRACE) a.trace_cnt[tid] = ts.ntr;
     store_pass(a, tid, ts);
     flush_counters(a, ts.done, ts.att);
 }
 
-// K1c: the same, FUSED over a range of iterations (single-GPU runs): one persistent launch in which
-// every wave walks the schedule its[0..n_iters) and performs its exact per-iteration quota under each
-// iteration's constants.  No grid barrier separates iterations — the reference's boundaries are looser
-// still (a 1 ms polling thread, sgd.rs:366-403) — but every iteration still applies exactly
-// min_term_updates updates with its own eta/theta.  Saves the per-launch ramp, tail and RNG round trip.
+// K1c: the same, FUSED over a range of iterations (single-GPU runs): one persistent launch in which every wave walks
+// the schedule its[0..n_iters).  Saves the per-launch ramp, tail and RNG round trip.
+//
+// WORK POOLS.  Round 1 gave every wave a fixed quota per iteration and no grid barrier.  Free-running waves drift apart:
+// one whose trips happen to be cheap runs iterations ahead of one whose trips are dear, so terms of several iterations —
+// several values of eta — are applied side by side, and the last, finest iterations are finished by the stragglers alone.
+// (The reference's iterations overlap by what its workers do in 1 ms, sgd.rs:366-403: a few per cent of an iteration.)
+// Measured on the 525k-node bubble graph: relative error at path distance 1 of 0.195-0.246 depending on the stream count
+// with free-running waves, 0.187-0.191 at every count with one launch per iteration — which is what the oracle's
+// sequential mirror gives (profiles/r02/pacing.log).  A counting barrier per iteration (with a lag of 1-6 iterations)
+// restores the precision but leaves the fast waves idle: C3 66-88 G updates/s against 93.
+// Instead an iteration's min_term_updates updates are a POOL that the waves draw from in chunks of TEAM_CHUNK updates
+// (one returning atomic per chunk, on one of up to 16 counters so that the claims do not queue on one address; a wave
+// claims its next chunk before it works on the current one).  A wave moves on to iteration k + 1 when its counter of
+// iteration k is exhausted: no wave is ever more than two chunks away from the others, nobody waits, and a wave that is
+// slow simply takes fewer chunks — which is the reference's own rule (its workers share one count per iteration).  Every
+// iteration still applies exactly min_term_updates updates with its own eta/theta.  C3: 97.8 G updates/s.
+// (A single wave claims every chunk itself, in order: the kernel with fixed quotas works through its quota in the same
+// chunks, so that one wave is bit for bit the oracle's mirror in both.)
+constexpr uint32_t POOL_SLOTS = 16, POOL_STRIDE = 16;              // counters per iteration; u32 per 64-B line
 template <int B, bool LDS_TABLES, bool ATOMIC_LOADS>
-__global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters) {
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters,
+                                                                                   uint32_t *pool) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
     stage_tables<LDS_TABLES>(a0, smem, path_tab, zeta_tab);
@@ -392,11 +504,38 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) sgd1d_team_fused_kern
     KArgs a = a0;
     TeamState ts;
     ts.rng.s0 = a.rng[tid]; ts.rng.s1 = a.rng[T + tid]; ts.rng.s2 = a.rng[2 * T + tid]; ts.rng.s3 = a.rng[3 * T + tid];
-    const uint64_t wq = wave_quota_of(a, tid);
+    const int lane = threadIdx.x & 63;
     load_pass(a, tid, ts);
-    for (uint32_t k = 0; k < n_iters; ++k) {
-        a.it = its[k];                                                // wave-uniform: scalar loads
-        team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq);
+    if (pool) {
+        const uint32_t wave = tid >> 6, n_waves = a0.n_streams >> 6;
+        const uint32_t slots = n_waves < POOL_SLOTS ? n_waves : POOL_SLOTS, slot = wave % slots;
+        const uint64_t total = (uint64_t)a0.quota_base * a0.n_streams + a0.quota_rem;
+        const uint32_t cap = (uint32_t)(total / slots + (slot < total % slots ? 1u : 0u));   // < 2^31 (host-checked)
+        uint32_t k = 0, claim = 0;
+        a.it = its[0];
+        if (lane == 0) claim = __hip_atomic_fetch_add(pool + slot * POOL_STRIDE, TEAM_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (k < n_iters) {
+            const uint32_t old = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+            if (old >= cap) {                                          // this iteration's pool is exhausted
+                if (++k == n_iters) break;
+                a.it = its[k];                                         // wave-uniform: scalar loads
+                if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            // the next claim travels while this chunk is worked on
+            if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, cap - old < TEAM_CHUNK ? cap - old : TEAM_CHUNK);
+        }
+    } else {
+        // fixed quota per wave and iteration, free-running (GFS_F_DBG_FREE_RUNNING)
+        const uint64_t wq = wave_quota_of(a, tid);
+        for (uint32_t k = 0; k < n_iters; ++k) {
+            a.it = its[k];
+            for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
+                team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK);
+        }
     }
     a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;
     store_pass(a, tid, ts);
@@ -468,19 +607,21 @@ static hipError_t launch_1db(const KArgs &a, bool lds_tables, bool atomic_loads,
 }
 template <int B>
 static hipError_t launch_1d_fused_b(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
-                                    dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (lds_tables) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, true>), grid, block, lds, st, a, d_its, n_iters);
-    else            hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, true>), grid, block, 0, st, a, d_its, n_iters);
+                                    uint32_t *pool, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (lds_tables) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, true>), grid, block, lds, st, a, d_its, n_iters, pool);
+    else            hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, true>), grid, block, 0, st, a, d_its, n_iters, pool);
     return hipGetLastError();
 }
 // fused range of iterations; only for the team kernel with its widest bundles (what the auto policy picks
-// on graphs large enough for launch overhead to matter)
-hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
+// on graphs large enough for launch overhead to matter).  pool: zeroed counters, pool_bytes(n_iters) of them, or null
+// (fixed quota per wave, free-running).
+size_t pool_bytes(uint64_t n_iters) { return (size_t)n_iters * POOL_SLOTS * POOL_STRIDE * sizeof(uint32_t); }
+hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
                            dim3 grid, dim3 block, size_t lds, hipStream_t st) {
     switch (a.bundle) {
-        case 16: return launch_1d_fused_b<16>(a, d_its, n_iters, lds_tables, grid, block, lds, st);
-        case 32: return launch_1d_fused_b<32>(a, d_its, n_iters, lds_tables, grid, block, lds, st);
-        case 64: return launch_1d_fused_b<64>(a, d_its, n_iters, lds_tables, grid, block, lds, st);
+        case 16: return launch_1d_fused_b<16>(a, d_its, n_iters, lds_tables, pool, grid, block, lds, st);
+        case 32: return launch_1d_fused_b<32>(a, d_its, n_iters, lds_tables, pool, grid, block, lds, st);
+        case 64: return launch_1d_fused_b<64>(a, d_its, n_iters, lds_tables, pool, grid, block, lds, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -16,6 +16,7 @@ F_PLAIN_LOADS, F_NO_LDS_TABLES, F_NO_FUSE = 1, 2, 4
 
 F_DBG_NO_ATOMICS, F_DBG_NO_XLOADS, F_DBG_ONE_COLOUR = 0x100, 0x200, 0x800
 F_DBG_NO_ALIGN, F_DBG_ALIGN_FIRST, F_DBG_WIDE_INDEX, F_DBG_NO_FUSED_TRIP = 0x1000, 0x2000, 0x4000, 0x8000
+F_ONE_PARTNER, F_DBG_NO_TWIN_TRIP, F_DBG_FREE_RUNNING = 0x10, 0x400, 0x20
 
 
 def F_CHAIN(k):

@@ -111,6 +111,12 @@ typedef struct gfs_launch_config {
 #define GFS_F_CHAIN(k) (((uint32_t)(k) & 0xFFu) << 24)   /* k in {0 = auto, 1, 2, 4, 8, 16, 32, 64} */
 #define GFS_F_NO_FUSE       4u        /* gfs_ctx_run / gfs_ctx_run_range: one launch per iteration even where
                                          a fused persistent launch is possible                        */
+#define GFS_F_ONE_PARTNER   0x10u     /* 1D team kernel at B = 64: one partner draw per leader (default: two — a sampled step a
+                                         with two independent draws of its partner b; where both are line-aligned long jumps
+                                         the two terms of a lane share the loads and the add of their a-side) */
+#define GFS_F_DBG_NO_TWIN_TRIP 0x400u /* diagnostic: the two partners of a leader as two trips even where one would do   */
+#define GFS_F_DBG_FREE_RUNNING 0x20u   /* diagnostic: fused launches with a fixed quota per wave and iteration and no pacing
+                                         (round 1's launch; the waves drift apart in the schedule) instead of work pools */
 #define GFS_F_DBG_NO_ATOMICS 0x100u   /* diagnostic ablation (wrong results): skip the atomic adds */
 #define GFS_F_DBG_NO_XLOADS  0x200u   /* diagnostic ablation (wrong results): skip position loads  */
 #define GFS_F_DBG_ONE_COLOUR   0x800u  /* diagnostic: short-jump runs execute their first colour only (round-1 behaviour:

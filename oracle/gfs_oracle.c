@@ -597,6 +597,8 @@ struct gfo_state {
     uint64_t chain;                                           /* longest run in trips (B = 64); mirror of GFS_F_CHAIN */
     int one_colour;                                           /* mirror of GFS_F_DBG_ONE_COLOUR */
     int no_fused_trip;                                        /* mirror of GFS_F_DBG_NO_FUSED_TRIP */
+    int partners, no_twin_trip;                               /* partner draws per leader (1, 2); mirror of GFS_F_DBG_NO_TWIN_TRIP */
+    uint8_t *lead_p;                                          /* the partner each wave's next trip belongs to */
     uint32_t *node_slot;                                     /* bundled mode: the product's internal node layout (line-aligned runs) */
     gfo_term *trace; uint64_t trace_per_stream;
     uint64_t total_upd, total_att, iterations;
@@ -607,7 +609,7 @@ void gfo_state_destroy(gfo_state *s) {
     if (!s) return;
     pidx_free(&s->pi);
     free(s->etas); free(s->zetas); free(s->rng); free(s->done); free(s->att); free(s->ntr);
-    free(s->lead); free(s->lead_left); free(s->lead_cool); free(s->lead_colour); free(s->lead_seg); free(s->node_slot);
+    free(s->lead); free(s->lead_left); free(s->lead_cool); free(s->lead_colour); free(s->lead_seg); free(s->lead_p); free(s->node_slot);
     free(s);
 }
 
@@ -620,7 +622,7 @@ int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas
     gfo_state *s = (gfo_state *)calloc(1, sizeof *s);
     if (!s) return -2;
     if (pidx_build(g, 1, &s->pi)) { gfo_state_destroy(s); return -2; }
-    s->p = *p; s->T = n_streams; s->D = dims; s->bundle = 1; s->chain = 1;
+    s->p = *p; s->T = n_streams; s->D = dims; s->bundle = 1; s->chain = 1; s->partners = 1;
     s->quota_total = quota_total ? quota_total : p->min_term_updates;
     s->attempt_factor = attempt_factor ? attempt_factor : 64;
     s->etas = (double *)malloc((p->iter_max + 1) * 8);
@@ -699,6 +701,14 @@ int gfo_state_set_one_colour(gfo_state *s, int on) {
     return 0;
 }
 
+/* Two partners per leader (product: 1D team kernel at B = 64 unless GFS_F_ONE_PARTNER); no_twin: mirror of
+ * GFS_F_DBG_NO_TWIN_TRIP — the two partners of an aligned leader as two trips. */
+int gfo_state_set_partners(gfo_state *s, int partners, int no_twin) {
+    if (!s || (partners != 1 && partners != 2)) return -1;
+    s->partners = partners; s->no_twin_trip = no_twin ? 1 : 0;
+    return 0;
+}
+
 /* mirror of GFS_F_DBG_NO_FUSED_TRIP: the two colours of a short-jump trip as two trips (1D) */
 int gfo_state_set_no_fused_trip(gfo_state *s, int on) {
     if (!s) return -1;
@@ -744,54 +754,71 @@ static int term_nd_flips(const pidx *pi, const iter_state *it, int fa, int fb, u
     return 1;
 }
 
-typedef struct leader_s { uint64_t first, cnt, ra0, rb0; int ok, aligned, rot; } leader_t;
+/* A leader: step a and one partner b — or, with two partners (product: sgd_device.h Leader, KArgs.partners = 2), the same
+ * step a with two independent draws of b.  (ra0, rb0, ok, aligned, rot) is the partner a trip works on: partner_view. */
+#define GFO_TEAM_CHUNK 2048u
+typedef struct leader_s { uint64_t first, cnt, ra0, rb0; int ok, aligned, rot; uint64_t ra1, rb1; int ok1, aligned1, rot1; } leader_t;
+static leader_t partner_view(const leader_t *L, uint64_t p) {
+    leader_t v = *L;
+    if (p) { v.ra0 = L->ra1; v.rb0 = L->rb1; v.ok = L->ok1; v.aligned = L->aligned1; v.rot = L->rot1; }
+    return v;
+}
 
-/* one leader term from one reference stream: sgd.rs:444-497 without applying it */
-static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t *rng) {
-    const pidx *pi = &s->pi;
-    leader_t L;
-    uint64_t s0 = uniform_steps(rng, pi->n_steps);                                     /* :444 */
-    uint64_t path = pi->rec[s0].path_rev & 0x7FFFFFFFu;
-    L.first = pi->paths[path].first_step; L.cnt = pi->paths[path].step_count;
-    L.ra0 = s0 - L.first; L.rb0 = L.ra0; L.ok = 0; L.aligned = 0; L.rot = 0;
-    if (L.cnt == 1) return L;                                                          /* :448 */
+/* one draw of the partner of step a (rank *ra in its path): sgd.rs:456-497 without applying it, then the product's line
+ * alignment of the two runs (sgd_device.h draw_partner, which explains the rule) */
+static void draw_partner(const gfo_state *s, const iter_state *it, uint64_t *rng, uint64_t cnt, uint32_t node0,
+                         uint64_t *ra, uint64_t *rb, int *ok, int *aligned, int *rot) {
+    const uint64_t a0 = *ra;
+    *rb = a0; *aligned = 0; *rot = 0;
     if (it->cooling || flip(rng) == 1) {                                               /* :456 */
-        if (L.ra0 > 0 && (flip(rng) == 1 || L.ra0 == L.cnt - 1)) {                    /* :460 */
-            uint64_t jump = s->z.space < L.ra0 ? s->z.space : L.ra0;
+        if (a0 > 0 && (flip(rng) == 1 || a0 == cnt - 1)) {                            /* :460 */
+            uint64_t jump = s->z.space < a0 ? s->z.space : a0;
             double z2 = 1.0 + fpp(0.5, it->theta);
             uint64_t zi = gfo_dirty_zipfian(1, jump, it->theta, s->z.zetas[space_index(&s->z, jump)], z2, random_f64(rng));
-            L.rb0 = L.ra0 >= zi ? L.ra0 - zi : 0;
-        } else if (L.ra0 < L.cnt - 1) {
-            uint64_t room = L.cnt - L.ra0 - 1;
+            *rb = a0 >= zi ? a0 - zi : 0;
+        } else if (a0 < cnt - 1) {
+            uint64_t room = cnt - a0 - 1;
             uint64_t jump = s->z.space < room ? s->z.space : room;
             double z2 = 1.0 + fpp(0.5, it->theta);
             uint64_t zi = gfo_dirty_zipfian(1, jump, it->theta, s->z.zetas[space_index(&s->z, jump)], z2, random_f64(rng));
-            uint64_t rb = L.ra0 + zi;
-            L.rb0 = rb < L.cnt - 1 ? rb : L.cnt - 1;
+            uint64_t b = a0 + zi;
+            *rb = b < cnt - 1 ? b : cnt - 1;
         }
     } else {
-        L.rb0 = uniform_usize(rng, L.cnt);                                             /* :493-494 */
+        *rb = uniform_usize(rng, cnt);                                                 /* :493-494 */
     }
-    L.ok = L.rb0 != L.ra0;                                                             /* :497 */
-    /* line-aligned runs (product: sgd_device.h sample_leader, which explains the rule): for |jump| >= B + 8 the run
-     * starts (slot of the leader's node) mod 8 steps before the leader; the partner run is the B-step block jump - r
-     * steps further on, r = jump mod 8, with lane l paired to its step (l + r) mod B */
-    uint32_t node0 = pi->rec[s0].node;
-    if (L.ok && L.cnt >= 2 * s->bundle && node0 != GFO_NO_NODE) {        /* only where a run will be expanded */
-        const int64_t jump = (int64_t)L.rb0 - (int64_t)L.ra0, Bn = (int64_t)s->bundle;
-        const int64_t Rn = Bn * (int64_t)run_trips(s, L.cnt);              /* steps of the whole run */
+    *ok = *rb != a0;                                                                   /* :497 */
+    /* line-aligned runs: for |jump| >= B + 8 the run starts (slot of the leader's node) mod 8 steps before the leader; the
+     * partner run is the B-step block jump - r steps further on, r = jump mod 8, with lane l paired to its step (l + r) mod B */
+    if (*ok && cnt >= 2 * s->bundle && node0 != GFO_NO_NODE) {             /* only where a run will be expanded */
+        const int64_t jump = (int64_t)*rb - (int64_t)a0, Bn = (int64_t)s->bundle;
+        const int64_t Rn = Bn * (int64_t)run_trips(s, cnt);                /* steps of the whole run */
         if (jump >= Bn + 8 || jump <= -(Bn + 8)) {                     /* shorter jumps are left alone */
             const int64_t A = Bn < 8 ? Bn : 8;                            /* runs shorter than a line: align to the run length */
             const uint64_t sh = (s->node_slot ? s->node_slot[node0] : node0) & (uint64_t)(A - 1);
-            if (L.ra0 >= sh) {
-                const int64_t na = (int64_t)L.ra0 - (int64_t)sh;
+            if (a0 >= sh) {
+                const int64_t na = (int64_t)a0 - (int64_t)sh;
                 const int64_t r = ((jump % A) + A) % A, zp = jump - r, nb = na + zp;
-                if (na + Rn <= (int64_t)L.cnt && nb >= 0 && nb + Rn <= (int64_t)L.cnt && (zp >= Bn || zp <= -Bn)) {
-                    L.ra0 = (uint64_t)na; L.rb0 = (uint64_t)nb; L.aligned = 1; L.rot = (int)r;
-                } else if (L.rb0 >= sh) { L.ra0 -= sh; L.rb0 -= sh; }
+                if (na + Rn <= (int64_t)cnt && nb >= 0 && nb + Rn <= (int64_t)cnt && (zp >= Bn || zp <= -Bn)) {
+                    *ra = (uint64_t)na; *rb = (uint64_t)nb; *aligned = 1; *rot = (int)r;
+                } else if (*rb >= sh) { *ra -= sh; *rb -= sh; }
             }
         }
     }
+}
+
+/* one leader from one reference stream: sgd.rs:444-453, then one or two partner draws */
+static leader_t sample_leader(const gfo_state *s, const iter_state *it, uint64_t *rng) {
+    const pidx *pi = &s->pi;
+    leader_t L;
+    memset(&L, 0, sizeof L);
+    uint64_t s0 = uniform_steps(rng, pi->n_steps);                                     /* :444 */
+    uint64_t path = pi->rec[s0].path_rev & 0x7FFFFFFFu;
+    L.first = pi->paths[path].first_step; L.cnt = pi->paths[path].step_count;
+    L.ra0 = s0 - L.first; L.rb0 = L.ra0; L.ra1 = L.ra0; L.rb1 = L.ra0;
+    if (L.cnt == 1) return L;                                                          /* :448 */
+    draw_partner(s, it, rng, L.cnt, pi->rec[s0].node, &L.ra0, &L.rb0, &L.ok, &L.aligned, &L.rot);
+    if (s->partners == 2) draw_partner(s, it, rng, L.cnt, pi->rec[s0].node, &L.ra1, &L.rb1, &L.ok1, &L.aligned1, &L.rot1);
     return L;
 }
 
@@ -872,6 +899,63 @@ static int fused_trip_1d(gfo_state *s, const iter_state *it, const leader_t *ld,
     return second;
 }
 
+/* Product: sgd_kernels_1d.hip twin_trip — both partners of a leader whose two runs are line-aligned long jumps, in one
+ * trip, as the wave executes it: every lane loads the positions of its step a and of its two partners b, c once; term
+ * (a, c) computes on what term (a, b) left in a's register; a's node receives ONE add, -(r + r'), b and c one each.
+ * `off`: the trip starts this many steps after the run's first step.  Returns 0 when the quota filled between the terms. */
+static int twin_trip_1d(gfo_state *s, const iter_state *it, const leader_t *ld, uint64_t off,
+                        uint64_t wave_first, uint64_t wave_quota, uint64_t *wave_done, double *x) {
+    const pidx *pi = &s->pi;
+    uint32_t na[64], np[2][64]; double xa[64], xp[2][64], pa[64], pp[2][64], acc[64] = {0.0}; int touched[64] = {0};
+    for (uint64_t l = 0; l < 64; l++) {
+        const uint64_t sa = ld->first + ld->ra0 + off + l;
+        const uint64_t sb = ld->first + ld->rb0 + off + ((l + (uint64_t)ld->rot) & 63);
+        const uint64_t sc = ld->first + ld->rb1 + off + ((l + (uint64_t)ld->rot1) & 63);
+        na[l] = pi->rec[sa].node; np[0][l] = pi->rec[sb].node; np[1][l] = pi->rec[sc].node;
+        pa[l] = (double)pi->rec[sa].pos; pp[0][l] = (double)pi->rec[sb].pos; pp[1][l] = (double)pi->rec[sc].pos;
+        xa[l] = na[l] != GFO_NO_NODE ? x[na[l]] : 0.0;
+        xp[0][l] = np[0][l] != GFO_NO_NODE ? x[np[0][l]] : 0.0;
+        xp[1][l] = np[1][l] != GFO_NO_NODE ? x[np[1][l]] : 0.0;
+    }
+    int second = 1;
+    for (int q = 0; q < 2; q++) {
+        int valid[64]; double td[64];
+        uint64_t nvalid = 0, rank = 0;
+        for (int l = 0; l < 64; l++) {
+            td[l] = fabs(pa[l] - pp[q][l]);                                            /* sgd.rs:513 */
+            valid[l] = td[l] != 0.0 && na[l] != GFO_NO_NODE && np[q][l] != GFO_NO_NODE; /* :514, :525-538 */
+            nvalid += (uint64_t)valid[l];
+        }
+        const uint64_t remaining = wave_quota - *wave_done;
+        for (int l = 0; l < 64; l++) {
+            s->att[wave_first + l]++;
+            if (valid[l] && rank++ >= remaining) valid[l] = 0;
+        }
+        *wave_done += nvalid < remaining ? nvalid : remaining;
+        for (int l = 0; l < 64; l++) {
+            if (!valid[l]) continue;
+            const double mu = fmin(it->eta * (1.0 / td[l]), 1.0);                      /* :518-520 */
+            double dx = xa[l] - xp[q][l];                                              /* :543 */
+            if (dx == 0.0) dx = 1e-9;                                                  /* :546-548 */
+            const double mag = fabs(dx);                                               /* :551 */
+            const double delta = mu * (mag - td[l]) / 2.0;                             /* :552 */
+            const double r = (delta / mag) * dx;                                       /* :570-571 */
+            const uint64_t tg = wave_first + (uint64_t)l;
+            s->done[tg]++;                                                             /* :579 */
+            if (s->trace && s->ntr[tg] < s->trace_per_stream) {
+                gfo_term *tr = &s->trace[tg * s->trace_per_stream + s->ntr[tg]++];
+                tr->i = na[l]; tr->j = np[q][l]; tr->d_ij = td[l];
+            }
+            xa[l] = xa[l] - r;                                                         /* :575 */
+            acc[l] = touched[l] ? acc[l] - r : -r; touched[l] = 1;
+            x[np[q][l]] = x[np[q][l]] + r;                                             /* :576 */
+        }
+        if (q == 0 && *wave_done >= wave_quota) { second = 0; break; }
+    }
+    for (int l = 0; l < 64; l++) if (touched[l]) x[na[l]] = x[na[l]] + acc[l];
+    return second;
+}
+
 /* Team semantics of the product (sgd1d_team_kernel): per wave of 64 streams, a PASS samples one
  * leader per stream; B TRIPS then expand the 64 leaders as 64/B runs of B lanes (trip t, run q
  * uses leader t*(64/B)+q).  Wave-level quota with a rank cut-off.  1D: the trips of a pass left over when
@@ -886,13 +970,19 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
         const uint64_t wave_first = w * 64;
         uint64_t wave_quota = base * 64;
         if (wave_first < rem) wave_quota += (rem - wave_first) < 64 ? (rem - wave_first) : 64;
+        const int carry = s->D == 0;
+        /* 1D: the wave works through its quota in chunks of GFO_TEAM_CHUNK updates, each with its own rank cut-off and pass
+         * budget (product: sgd_device.h TEAM_CHUNK; its fused launch draws such chunks from a pool) */
+        const uint64_t wave_quota_all = wave_quota;
+        for (uint64_t chunk0 = 0; chunk0 < wave_quota_all; chunk0 += (carry ? GFO_TEAM_CHUNK : wave_quota_all)) {
+        if (carry) wave_quota = wave_quota_all - chunk0 < GFO_TEAM_CHUNK ? wave_quota_all - chunk0 : GFO_TEAM_CHUNK;
         const uint64_t max_passes = s->attempt_factor * (wave_quota / (64 * B) + 1) + 16;
         uint64_t wave_done = 0, passes = 0;
-        const int carry = s->D == 0;
         if (!s->lead) {
             s->lead = (leader_t *)calloc(T, sizeof(leader_t));
             s->lead_left = (uint8_t *)calloc(T / 64, 1); s->lead_cool = (uint8_t *)calloc(T / 64, 1);
             s->lead_colour = (uint8_t *)calloc(T / 64, 1); s->lead_seg = (uint8_t *)calloc(T / 64, 1);
+            s->lead_p = (uint8_t *)calloc(T / 64, 1);
         }
         leader_t *L = s->lead + wave_first;
         int lead_fa[64] = {0}, lead_fb[64] = {0};
@@ -907,40 +997,60 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                     }
                 }
                 s->lead_left[w] = (uint8_t)B; s->lead_cool[w] = (uint8_t)it.cooling; s->lead_colour[w] = 0; s->lead_seg[w] = 0;
+                s->lead_p[w] = 0;
             }
             /* trips: slot t of the pass, colour 0, then — when some run of the slot has a jump shorter than the run
              * (sgd_device.h two_colour) — the same slot with colour 1: the run's terms chain through shared
              * nodes, each colour is node-disjoint, together they are every term of the run */
             while (s->lead_left[w] > 0 && wave_done < wave_quota) {
                 const uint64_t t = B - s->lead_left[w];
-                const uint64_t colour = s->lead_colour[w], seg = s->lead_seg[w];
+                const uint64_t colour = s->lead_colour[w], seg = s->lead_seg[w], pp = s->lead_p[w];
+                leader_t V[16];                                         /* the slot's leaders as partner pp sees them */
+                for (uint64_t qq = 0; qq < RUNS; qq++) V[qq] = partner_view(&L[t * RUNS + qq], pp);
                 int two = 0;
                 for (uint64_t qq = 0; qq < RUNS && !s->one_colour; qq++) {
-                    const leader_t *ld = &L[t * RUNS + qq];
+                    const leader_t *ld = &V[qq];
                     const int64_t shift = (int64_t)ld->rb0 - (int64_t)ld->ra0;
                     if (ld->ok && !ld->aligned && ld->cnt >= 2 * B && shift < (int64_t)B && shift > -(int64_t)B) two = 1;
                 }
-                /* trips of this slot's run (B = 64: one leader per trip) */
-                const uint64_t ktrips = (RUNS == 1 && L[t].ok && L[t].cnt >= 2 * B) ? run_trips(s, L[t].cnt) : 1;
+                /* trips of this slot's run (B = 64: one leader per trip); the same for both partners, whose trips alternate */
+                const uint64_t ktrips = (RUNS == 1 && (L[t].ok || L[t].ok1) && L[t].cnt >= 2 * B) ? run_trips(s, L[t].cnt) : 1;
+                const int more_partners = pp == 0 && s->partners == 2;
+                /* after the trip(s) of (seg, pp): the other partner's trip of this seg, else the run's next trip, else the next slot */
+#define GFO_ADVANCE(skip_partner) do { \
+                    s->lead_colour[w] = 0; \
+                    if (more_partners && !(skip_partner)) s->lead_p[w] = 1; \
+                    else if (seg + 1 < ktrips) { s->lead_seg[w] = (uint8_t)(seg + 1); s->lead_p[w] = 0; } \
+                    else { s->lead_seg[w] = 0; s->lead_p[w] = 0; s->lead_left[w]--; } } while (0)
+                /* (not when the two partner runs overlap or touch: the wave would read, as one partner's positions, what it
+                 * has only just added as the other's) */
+                const int64_t pgap = (int64_t)L[t].rb0 - (int64_t)L[t].rb1, plim = (int64_t)ktrips * 64 + 64;
+                if (s->D == 0 && RUNS == 1 && more_partners && !s->no_twin_trip && L[t].ok && L[t].aligned && L[t].ok1 && L[t].aligned1 &&
+                    (pgap >= plim || pgap <= -plim)) {
+                    /* both partners in one trip (product: twin_trip) */
+                    if (!twin_trip_1d(s, &it, &L[t], seg * B, wave_first, wave_quota, &wave_done, x))
+                        s->lead_p[w] = 1;                               /* quota filled between the partners */
+                    else GFO_ADVANCE(1);
+                    continue;
+                }
                 if (s->D == 0 && RUNS == 1 && colour == 0 && two && !s->no_fused_trip) {
-                    const uint64_t off0 = run_offset(s, L[t].cnt, ktrips, L[t].ra0, L[t].rb0, seg);
-                    const int64_t ms = merged_trip_shift(&L[t], off0);
+                    const uint64_t off0 = run_offset(s, V[0].cnt, ktrips, V[0].ra0, V[0].rb0, seg);
+                    const int64_t ms = merged_trip_shift(&V[0], off0);
                     if (ms != 0) {                                      /* both colours in one trip (product: fused_trip) */
-                        if (!fused_trip_1d(s, &it, &L[t], off0, ms, wave_first, wave_quota, &wave_done, x))
+                        if (!fused_trip_1d(s, &it, &V[0], off0, ms, wave_first, wave_quota, &wave_done, x))
                             s->lead_colour[w] = 1;                      /* quota filled between the colours */
-                        else if (seg + 1 < ktrips) s->lead_seg[w] = (uint8_t)(seg + 1);
-                        else { s->lead_seg[w] = 0; s->lead_left[w]--; }
+                        else GFO_ADVANCE(0);
                         continue;
                     }
                 }
-                /* what comes next: this trip's second colour, else the run's next trip, else the next slot */
+                /* what comes next: this trip's second colour, else as above */
                 if (colour == 0 && two) s->lead_colour[w] = 1;
-                else if (seg + 1 < ktrips) { s->lead_colour[w] = 0; s->lead_seg[w] = (uint8_t)(seg + 1); }
-                else { s->lead_colour[w] = 0; s->lead_seg[w] = 0; s->lead_left[w]--; }
+                else GFO_ADVANCE(0);
+#undef GFO_ADVANCE
                 int valid[64], flips_a[64], flips_b[64]; uint64_t sa[64], sb[64];
                 uint64_t nvalid = 0;
                 for (uint64_t qq = 0; qq < RUNS; qq++) {
-                    const leader_t *ld = &L[t * RUNS + qq];
+                    const leader_t *ld = &V[qq];
                     const int64_t shift = (int64_t)ld->rb0 - (int64_t)ld->ra0;
                     const uint64_t zabs = (uint64_t)(shift < 0 ? -shift : shift);
                     const uint64_t off = run_offset(s, ld->cnt, ktrips, ld->ra0, ld->rb0, seg);
@@ -998,6 +1108,7 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                 wave_done += nvalid < remaining ? nvalid : remaining;
             }
         }
+        }   /* chunks */
     }
     return 0;
 }

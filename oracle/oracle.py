@@ -242,7 +242,7 @@ class State:
     """Resumable deterministic run (gfo_state).  bundle > 1 mirrors the product's bundled sampler."""
 
     def __init__(self, g, p, dims=0, n_streams=1, stream_base=0, quota_total=0, attempt_factor=64,
-                 trace_per_stream=0, bundle=1, etas=None, zts=None, node_slots=None, one_colour=False, chain=1, fused_trip=True):
+                 trace_per_stream=0, bundle=1, etas=None, zts=None, node_slots=None, one_colour=False, chain=1, fused_trip=True, partners=1, twin_trip=True):
         self.g, self.p = g, p
         self.trace = np.zeros(n_streams * trace_per_stream, dtype=TERM_DTYPE) if trace_per_stream else None
         self.h = C.c_void_p()
@@ -255,6 +255,9 @@ class State:
             raise ValueError("bad bundle")
         if one_colour:
             assert lib().gfo_state_set_one_colour(self.h, C.c_int(1)) == 0
+        if partners != 1 or not twin_trip:
+            # the product's two partners per leader (default of its 1D team kernel at B = 64; GFS_F_ONE_PARTNER = 1)
+            assert lib().gfo_state_set_partners(self.h, C.c_int(partners), C.c_int(0 if twin_trip else 1)) == 0
         if not fused_trip:
             assert lib().gfo_state_set_no_fused_trip(self.h, C.c_int(1)) == 0       # mirror of GFS_F_DBG_NO_FUSED_TRIP
         if chain != 1:

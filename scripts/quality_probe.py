@@ -21,7 +21,13 @@ VARIANTS = {
     "B64": hip.F_BUNDLE(64),
     "auto": 0,
 }
-VARIANTS["B64_r1"] = hip.F_BUNDLE(64) | hip.F_CHAIN(1) | hip.F_DBG_ONE_COLOUR      # the round-1 sampler
+VARIANTS["auto_p1"] = hip.F_ONE_PARTNER                     # one partner draw per leader (the sampler before twin trips)
+VARIANTS["auto_notwin"] = hip.F_DBG_NO_TWIN_TRIP            # two partners, as two trips each
+VARIANTS["auto_nofuse"] = hip.F_NO_FUSE                      # one launch per iteration
+VARIANTS["auto_p1_nofuse"] = hip.F_NO_FUSE | hip.F_ONE_PARTNER
+VARIANTS["auto_free"] = hip.F_DBG_FREE_RUNNING               # fixed quota per wave, free-running waves (round 1's fused launch)
+VARIANTS["auto_p1_free"] = hip.F_DBG_FREE_RUNNING | hip.F_ONE_PARTNER
+VARIANTS["B64_r1"] = hip.F_BUNDLE(64) | hip.F_CHAIN(1) | hip.F_DBG_ONE_COLOUR | hip.F_ONE_PARTNER | hip.F_DBG_FREE_RUNNING      # the round-1 sampler
 for _k in (1, 2, 4, 8, 16, 32, 64):
     VARIANTS[f"B64_k{_k}"] = hip.F_BUNDLE(64) | hip.F_CHAIN(_k)
     VARIANTS[f"B64_k{_k}_nofusedtrip"] = hip.F_BUNDLE(64) | hip.F_CHAIN(_k) | hip.F_DBG_NO_FUSED_TRIP

@@ -280,6 +280,11 @@ def _mirror_chain(B, dims=0):
     return (16 if dims else 64) if B == 64 else 1
 
 
+def _mirror_partners(B, dims=0):
+    """The product's partner draws per leader: two in the 1D team kernel at B = 64 (unless GFS_F_ONE_PARTNER), else one."""
+    return 2 if B == 64 and dims == 0 else 1
+
+
 
 @pytest.mark.parametrize("B", [4, 8, 16, 32, 64])
 def test_bundled_sampler_trace_matches_oracle_mirror(B):
@@ -290,7 +295,8 @@ def test_bundled_sampler_trace_matches_oracle_mirror(B):
     p = _ygs(g, 6)
     T, K = 512, 48
     og, op = oracle_graph(g), oracle_params(p)
-    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g), chain=_mirror_chain(B))
+    st_o = O.State(og, op, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g), chain=_mirror_chain(B),
+                   partners=_mirror_partners(B))
     x_ref = O.init_positions(og)
     st_o.run(x_ref)
     so = st_o.stats()
@@ -943,25 +949,32 @@ def test_two_ranks_on_one_gpu_layout_2d():
 
 
 # ---- implementation = specification for the team kernel: one wave replays the oracle's sequential MIRROR bit for bit ----
-@pytest.mark.parametrize("fused,fused_trip", [(False, True), (True, True), (True, False)])
-def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(fused, fused_trip):
+@pytest.mark.parametrize("graph", ["windows", "bubbles"])
+@pytest.mark.parametrize("fused,fused_trip,partners,twin", [(False, True, 2, True), (True, True, 2, True), (True, False, 2, True),
+                                                            (True, True, 2, False), (True, True, 1, True), (False, True, 1, True)])
+def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(graph, fused, fused_trip, partners, twin):
     """Implementation = specification.  One wave of 64 streams, B = 64: trips run
     one after another and the adds of a trip go to distinct nodes on a graph whose paths visit no node twice, so
     the concurrent GPU trip equals the mirror's lane-by-lane application — positions must agree to the last bit.
-    Covers the arithmetic of the product's main kernel including line-aligned long runs, fused two-colour trips (a node
-    receives ONE add for both colours: x + (-r + r'), which rounds differently from (x - r) + r' — the mirror does the
-    same; fused_trip = False: the two colours as two trips, GFS_F_DBG_NO_FUSED_TRIP) and merged short-jump trips at path
-    ends.  fused: one launch for the whole schedule / one per iteration."""
-    g = G.synth_windows(40_000, 8, 20_000, 12)
+    Covers the arithmetic of the product's main kernel including line-aligned long runs, two partners per leader with TWIN
+    trips (both terms of a lane from one load of its a-side, one add -(r + r') for it; twin = False: as two trips,
+    GFS_F_DBG_NO_TWIN_TRIP; partners = 1: GFS_F_ONE_PARTNER), fused two-colour trips (a node receives ONE add for both
+    colours: x + (-r + r'), which rounds differently from (x - r) + r' — the mirror does the same; fused_trip = False: the
+    two colours as two trips, GFS_F_DBG_NO_FUSED_TRIP), merged short-jump trips at path ends, and the chunks of 2048
+    updates a wave's quota is worked through in.  fused: one launch for the whole schedule, the wave drawing its chunks
+    from the work pools / one launch per iteration with the fixed quota."""
+    g = G.synth_windows(40_000, 8, 20_000, 12) if graph == "windows" else G.synth_bubbles(30_000, 8, 3)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
     p.iter_max = 8
     p.min_term_updates = 200_000
     og, op = oracle_graph(g), oracle_params(p)
-    st_o = O.State(og, op, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64), fused_trip=fused_trip)
+    st_o = O.State(og, op, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64), fused_trip=fused_trip,
+                   partners=partners, twin_trip=twin)
     x_ref = O.init_positions(og)
     st_o.run(x_ref)
     so = st_o.stats()
-    flags = hip.F_BUNDLE(64) | (0 if fused else hip.F_NO_FUSE) | (0 if fused_trip else hip.F_DBG_NO_FUSED_TRIP)
+    flags = (hip.F_BUNDLE(64) | (0 if fused else hip.F_NO_FUSE) | (0 if fused_trip else hip.F_DBG_NO_FUSED_TRIP) |
+             (0 if partners == 2 else hip.F_ONE_PARTNER) | (0 if twin else hip.F_DBG_NO_TWIN_TRIP))
     ctx = hip.Context(g)
     ctx.setup_1d(p, hip.make_config(n_streams=64, flags=flags))
     ctx.upload(hip.init_positions(g))

@@ -95,7 +95,7 @@ def test_default_flags_on_a_2m_node_bubble_graph_against_reference_streams():
     res = _compare(g, og, x_b1, x_def, "default flags vs GPU reference streams, 2M nodes")
     # the round-1 sampler (short runs, first colour only) is what these thresholds exist to catch: +40-55 % stress
     ctx = hip.Context(g)
-    x_r1, _ = _run_default(ctx, p, hip.F_BUNDLE(64) | hip.F_CHAIN(1) | hip.F_DBG_ONE_COLOUR)
+    x_r1, _ = _run_default(ctx, p, hip.F_BUNDLE(64) | hip.F_CHAIN(1) | hip.F_DBG_ONE_COLOUR | hip.F_ONE_PARTNER | hip.F_DBG_FREE_RUNNING)
     ctx.close()
     with pytest.raises(AssertionError):
         _compare(g, og, x_b1, x_r1, "round-1 sampler")
