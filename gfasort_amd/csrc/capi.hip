@@ -402,13 +402,12 @@ static int upload_zeta_table(gfs_ctx *c, const gfs_sgd_params *p, const double *
 
 // Streams per launch when the caller leaves it to the library.
 static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
-    // 976 lanes per CU (just under 4 waves per SIMD; 249 856 on MI355X): each wave is a serial chain of memory round
-    // trips, so more chains raise throughput until the memory-side atomic units saturate.  Measured with the final
-    // kernels (profiles/r01/sweep_streams_final.log, defer_probe.log): C3 69.1 / 78.7 / 80.2 G updates/s at 512 / 768 /
-    // 976 lanes per CU, 600k nodes 66.7 / 75.6 / 77.7, C4 layout flat from 768 up; reference streams are flat within
-    // 5 % from 512 up.  (976 rather than 1024 keeps 4*streams <= 1e6 nodes, the deferral condition, on C3-sized graphs.)
-    // Round 2: the 1D team kernels are built for 5 waves per SIMD and get 1 280 lanes per CU (327 680 on MI355X): C3 77.5 G
-    // updates/s at 249 856 streams, 78.0 at 294 912, 80.0 at 327 680 (profiles/r02/streams_5_waves.log).
+    // Lanes per CU: each wave is a serial chain of memory round trips, so more chains raise throughput until the memory-side
+    // atomic units saturate.  Round 1 (profiles/r01/sweep_streams_final.log, defer_probe.log): C3 69.1 / 78.7 / 80.2 G
+    // updates/s at 512 / 768 / 976 lanes per CU, C4 layout flat from 768 up; reference streams flat within 5 % from 512 up.
+    // Round 2: the 1D team kernels run 4 waves per SIMD (128 VGPRs; twin trips keep three blocks of a trip in flight) = 1024
+    // lanes per CU; 5 waves (96 VGPRs) spill 58 registers and are slower (profiles/r02/two_partners.log).  The fused launch
+    // further bounds the count by the workgroups that are resident at once (setup_common).
     const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1024 : 976);
     // keep >= 8 updates per stream per batch on small graphs
     const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
@@ -416,11 +415,13 @@ static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
     // term corrects its two nodes from positions read before the others landed, so with ~2 concurrent
     // terms per node and mu clamped at 1 the corrections overshoot — a 6000-node graph of short paths
     // diverged (stress 1e8) under 6784 reference streams and converges under 1024
-    // (profiles/r01/stream_cap_probe.log).  The team kernels tolerate one stream per 2 nodes: bubble graphs
-    // of 26k / 79k / 197k nodes end at stress 0.0070 / 0.0040 / 0.0031 against 0.0069 / 0.0040 / 0.0029 at one
-    // per 4, and run 1.3-1.7x faster; at one per node the largest drifts to 0.0033, at two per node to
-    // 0.0071 (profiles/r01/stream_cap_mid.log).  An explicit n_streams overrides this.
-    const uint64_t by_nodes = (c->n_nodes / (team ? 2 : 4)) / 64 * 64;
+    // (profiles/r01/stream_cap_probe.log).  The team kernels tolerate three streams per 4 nodes: with the work pools of the
+    // fused launch, bubble graphs of 26k / 79k / 197k nodes keep their relative error at path distance 1 (0.194 / 0.206 /
+    // 0.192-0.197 against 0.198 / 0.208 / 0.191 at one stream per 2 nodes; reference streams 0.192 / 0.201 / 0.190) up to
+    // one stream per node and lose it at two (0.224 / 0.248 / 0.220), at 2.0 / 1.65 / 1.2 times the rate
+    // (profiles/r02/stream_cap_pools.log; round 1 allowed one per 2 nodes, measured with free-running waves whose drift
+    // cost precision by itself).  An explicit n_streams overrides this.
+    const uint64_t by_nodes = (team ? c->n_nodes * 3 / 4 : c->n_nodes / 4) / 64 * 64;
     return std::max<uint64_t>(64, std::min(chip, std::min(by_work, by_nodes)));
 }
 
