@@ -904,10 +904,6 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     fill_kargs(c, a);
     iter_consts(c, ks[0], a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
-    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
-    int rc = next_event_pair(c, ev);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(ev->first, st));
     // work pools (sgd_kernels_1d.hip): the waves draw an iteration's updates from shared counters, zeroed per launch.
     // (A share per counter beyond 2^31 — 3e10 updates per iteration — keeps the fixed quotas.)
     uint32_t *pool = nullptr;
@@ -922,6 +918,10 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
         HIPCHK(hipMemsetAsync(c->d_pool, 0, gfs::pool_bytes(n), st));
         pool = c->d_pool;
     }
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    int rc = next_event_pair(c, ev);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev->first, st));                // (the event pair brackets the kernel alone)
     hipError_t e = gfs::launch_1d_fused(a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st);
     if (e != hipSuccess) return fail(GFS_E_HIP, std::string("fused kernel launch: ") + hipGetErrorString(e));
     HIPCHK(hipEventRecord(ev->second, st));
