@@ -880,6 +880,17 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
         for (uint64_t i = 0; i < n; ++i) { int rc = gfs_ctx_run_iteration(c, ks[i], hip_stream); if (rc) return rc; }
         return GFS_OK;
     }
+    // a fused launch covers at most kMaxFusedIterations (its pool counters are 1 KB per iteration); longer ranges are
+    // consecutive launches on the stream
+    constexpr uint64_t kMaxFusedIterations = 4096;
+    if (n > kMaxFusedIterations) {
+        for (uint64_t off = 0; off < n; off += kMaxFusedIterations) {
+            const uint64_t m = std::min(kMaxFusedIterations, n - off);
+            int rc = m > 1 ? gfs_ctx_run_range(c, ks + off, m, hip_stream) : gfs_ctx_run_iteration(c, ks[off], hip_stream);
+            if (rc) return rc;
+        }
+        return GFS_OK;
+    }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)hip_stream;
     bool consecutive = c->d_its_all != nullptr;

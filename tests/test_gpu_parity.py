@@ -710,6 +710,25 @@ def test_fused_range_with_repeated_and_partial_schedules():
         ctx.close()
 
 
+def test_a_schedule_longer_than_one_fused_launch_covers():
+    """A fused launch covers at most 4096 iterations (its pool counters are 1 KB per iteration); a longer range is several
+    launches on the stream.  --iter-max 5000 on a small graph: exact counts, chain order."""
+    g = G.synth_windows(20_000, 4, 10_000, 9)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.iter_max = 5000
+    p.min_term_updates = 20_000
+    ctx = hip.Context(g)
+    ctx.setup_1d(p, hip.make_config(flags=hip.F_BUNDLE(64)))
+    ctx.init_positions()
+    ctx.run()
+    st = ctx.stats()
+    x = ctx.download()
+    ctx.close()
+    assert st.launches == 2 and st.iterations == 5001 and st.term_updates == 5001 * 20_000
+    ids = g.node_ids[hip.sort_order(x).astype(np.int64)].astype(np.int64)
+    assert np.all(np.diff(ids) == 1) or np.all(np.diff(ids) == -1)
+
+
 # ---- the real collective library: a ONE-rank RCCL group on the one GPU -----------------------------------------
 def _rccl_rank(port, out):
     """Everything bench.py does for N > 1 except having peers: RCCL init on cuda:0, the f32 [delta, touched]
