@@ -31,7 +31,8 @@ hipError_t warm_module_index();
 hipError_t init_positions_device(const uint32_t *d_node_len, const uint32_t *d_perm, double *d_x, uint64_t n);
 hipError_t reorder_positions_device(const double *d_src, double *d_dst, const uint32_t *d_perm, uint64_t N, uint32_t D,
                                     int to_device, hipStream_t st);
-hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_steps, uint64_t n_nodes, uint32_t *d_perm,
+hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_steps, uint64_t n_nodes, const uint64_t *d_path_first,
+                                     uint32_t n_paths, uint32_t *d_perm,
                                      int *bad_out);
 hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d_step_is_rev, const uint32_t *d_node_len,
                                    const uint32_t *d_perm, const uint64_t *d_path_first, uint32_t n_paths,
@@ -666,6 +667,10 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
         GFS_TRY("hipMalloc step_node", hipMalloc(&d_step_node, S * 4));
         GFS_TRY("hipMemcpy step_node", hipMemcpy(d_step_node, g->step_node, S * 4, hipMemcpyHostToDevice));
     }
+    if (S) {
+        GFS_TRY("hipMalloc path_first", hipMalloc(&d_first, (P + 1) * 8));
+        GFS_TRY("hipMemcpy path_first", hipMemcpy(d_first, g->path_first_step, (P + 1) * 8, hipMemcpyHostToDevice));
+    }
     lap("step upload");
     {
         // range check of step_node, and (unless the caller brought a layout) the first-visit order
@@ -673,7 +678,7 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
         uint32_t *d_scratch_perm = nullptr;
         uint32_t *target = c->d_perm;
         if (node_perm && N) { GFS_TRY("hipMalloc scratch", hipMalloc(&d_scratch_perm, N * 4)); target = d_scratch_perm; }
-        e = gfs::first_visit_layout_device(d_step_node, S, N, target, &bad);
+        e = gfs::first_visit_layout_device(d_step_node, S, N, d_first, (uint32_t)P, target, &bad);
         if (d_scratch_perm) (void)hipFree(d_scratch_perm);
         if (e != hipSuccess) { free_tmp(); return bail("first_visit_layout", e); }
         if (bad) { free_tmp(); gfs_ctx_destroy(c); return fail(GFS_E_ARG, "step_node out of range"); }
@@ -684,12 +689,10 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     if (S) {
         GFS_TRY("hipMalloc step_is_rev", hipMalloc(&d_rev, S));
 
-        GFS_TRY("hipMalloc path_first", hipMalloc(&d_first, (P + 1) * 8));
         GFS_TRY("hipMalloc scan", hipMalloc(&d_tmp, (S + 1) * 8));
         lap("alloc tmp");
         GFS_TRY("hipMemcpy step_is_rev", hipMemcpy(d_rev, g->step_is_rev, S, hipMemcpyHostToDevice));
 
-        GFS_TRY("hipMemcpy path_first", hipMemcpy(d_first, g->path_first_step, (P + 1) * 8, hipMemcpyHostToDevice));
         lap("upload");
         GFS_TRY("build_path_index", gfs::build_path_index_device(d_step_node, d_rev, c->d_node_len, c->d_perm, d_first, (uint32_t)P, S, N,
                                                                   d_tmp, c->d_step_rec, c->d_path_len));

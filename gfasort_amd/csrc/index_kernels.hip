@@ -108,11 +108,19 @@ hipError_t build_path_index_device(const uint32_t *d_step_node, const uint8_t *d
     return e != hipSuccess ? e : e2;
 }
 
-// ---- internal node layout (first-visit path order) --------------------------------------------------
-// perm[n] = number of distinct nodes the paths step on before they first step on n; nodes no path visits
-// follow in index order.  (What a scan over the steps with a counter gives; done here as min-reduction +
-// stable sort so that a 4.5e9-step graph takes 0.3 s instead of 25 s on one host core.)  The same pass
+// ---- internal node layout (first-visit path order with branches placed where they branch off) -----------------------
+// Base rule: nodes in the order the paths first step on them, nodes no path visits last in index order (min-reduction over
+// the steps + stable sort, so that a 4.5e9-step graph takes 0.3 s instead of 25 s on one host core).  The same pass
 // validates step_node (dense index < n_nodes, or NO_NODE).
+// Refinement: the first visits of a path come in RUNS of consecutive steps.  A run that starts its path is a ROOT run and
+// keeps its place.  Any other run BRANCHES OFF the node its path stepped on just before it (its anchor) — an alternative
+// allele of a bubble, first seen by the 7th haplotype, branches off the node before the bubble — and is placed right after
+// the root-run node its chain of anchors leads to, instead of where the 7th haplotype happens to come in step order.
+// sort key of node v = 2*first[v] for a root-run node, 2*first[root(v)] + 1 otherwise; ties (branches of one root node)
+// in first-visit order.  Why: a run of 64 consecutive path steps then touches neighbouring position words on a bubble
+// graph too, not 8 lines of main chain plus a scattered line per alternative allele (bubble graphs of 0.5M / 2M nodes:
+// 63.9 -> 77.6 and 68.2 -> 79.7 G updates/s, profiles/r02/relayout_probe.log; chains and window graphs are unchanged —
+// they have no branches).  gfs_shared_node_layout (multi.hip) is the same rule on the host.
 __global__ void first_visit_kernel(const uint32_t *step_node, uint64_t n_steps, uint64_t n_nodes,
                                    unsigned long long *first, int *bad) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -131,30 +139,90 @@ __global__ void scatter_rank_kernel(const uint32_t *sorted_node, uint32_t *perm,
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) perm[sorted_node[r]] = (uint32_t)r;
 }
+__device__ __forceinline__ bool is_path_start(const uint64_t *path_first, uint32_t n_paths, uint64_t s) {
+    uint32_t lo = 0, hi = n_paths;                                         // first path whose first step is >= s
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (path_first[mid] < s) lo = mid + 1; else hi = mid; }
+    return lo < n_paths && path_first[lo] == s;
+}
+// up[v] = v for the first node of a run of first visits (and for unvisited nodes), else the node visited just before it
+__global__ void run_up_kernel(const uint32_t *step_node, const unsigned long long *first, const uint64_t *path_first, uint32_t n_paths,
+                              uint64_t n_nodes, uint32_t *up) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_nodes; v += stride) {
+        const unsigned long long f = first[v];
+        uint32_t u = (uint32_t)v;
+        if (f != ~0ull && f > 0 && !is_path_start(path_first, n_paths, f)) {
+            const uint32_t p = step_node[f - 1];
+            if (p != 0xFFFFFFFFu && first[p] == f - 1) u = p;               // the previous step was a first visit too
+        }
+        up[v] = u;
+    }
+}
+// pointer jumping: out[v] = in[in[v]]
+__global__ void jump_kernel(const uint32_t *in, uint32_t *out, uint64_t n_nodes, int *changed) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_nodes; v += stride) {
+        const uint32_t a = in[v], b = in[a];
+        out[v] = b;
+        if (b != a) *changed = 1;
+    }
+}
+// anc[v] = v for a node of a root run (and unvisited nodes), else the node its run branches off; head[v] = first node of v's run
+__global__ void anchor_kernel(const uint32_t *step_node, const unsigned long long *first, const uint64_t *path_first, uint32_t n_paths,
+                              const uint32_t *head, uint64_t n_nodes, uint32_t *anc) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_nodes; v += stride) {
+        uint32_t a = (uint32_t)v;
+        if (first[v] != ~0ull) {
+            const unsigned long long fh = first[head[v]];
+            if (fh > 0 && !is_path_start(path_first, n_paths, fh)) {
+                const uint32_t p = step_node[fh - 1];
+                if (p != 0xFFFFFFFFu) a = p;
+            }
+        }
+        anc[v] = a;
+    }
+}
+// keys in first-visit order: key[r] for the node ids_by_first[r]
+__global__ void branch_key_kernel(const unsigned long long *first, const uint32_t *root, const uint32_t *ids_by_first, uint64_t n_nodes,
+                                  unsigned long long *key) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_nodes; r += stride) {
+        const uint32_t v = ids_by_first[r];
+        const unsigned long long f = first[v];
+        const uint32_t t = root[v];
+        key[r] = f == ~0ull ? ~0ull : (t == v ? 2ull * f : 2ull * first[t] + 1ull);
+    }
+}
 
-// d_perm: n_nodes u32 (device).  *bad_out = 1 when a step names a node >= n_nodes.  Synchronous.
-hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_steps, uint64_t n_nodes, uint32_t *d_perm,
-                                     int *bad_out) {
+// d_perm: n_nodes u32 (device).  d_path_first: [n_paths + 1] u64 (device).  *bad_out = 1 when a step names a node >= n_nodes.
+// Synchronous.
+hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_steps, uint64_t n_nodes, const uint64_t *d_path_first,
+                                     uint32_t n_paths, uint32_t *d_perm, int *bad_out) {
     *bad_out = 0;
     if (n_nodes == 0) return hipSuccess;
     unsigned long long *d_first = nullptr, *d_first_sorted = nullptr;
-    uint32_t *d_ids = nullptr, *d_ids_sorted = nullptr;
+    uint32_t *d_ids = nullptr, *d_ids_sorted = nullptr, *d_a = nullptr, *d_b = nullptr;
     int *d_bad = nullptr;
     void *d_tmp = nullptr;
     hipError_t e = hipSuccess;
     auto done = [&](hipError_t err) {
         (void)hipFree(d_first); (void)hipFree(d_first_sorted); (void)hipFree(d_ids); (void)hipFree(d_ids_sorted);
-        (void)hipFree(d_bad); (void)hipFree(d_tmp);
+        (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_bad); (void)hipFree(d_tmp);
         return err;
     };
     if ((e = hipMalloc(&d_first, n_nodes * 8)) != hipSuccess) return done(e);
     if ((e = hipMalloc(&d_first_sorted, n_nodes * 8)) != hipSuccess) return done(e);
     if ((e = hipMalloc(&d_ids, n_nodes * 4)) != hipSuccess) return done(e);
     if ((e = hipMalloc(&d_ids_sorted, n_nodes * 4)) != hipSuccess) return done(e);
-    if ((e = hipMalloc(&d_bad, sizeof(int))) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_a, n_nodes * 4)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_b, n_nodes * 4)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&d_bad, 2 * sizeof(int))) != hipSuccess) return done(e);
     if ((e = hipMemset(d_first, 0xFF, n_nodes * 8)) != hipSuccess) return done(e);
-    if ((e = hipMemset(d_bad, 0, sizeof(int))) != hipSuccess) return done(e);
+    if ((e = hipMemset(d_bad, 0, 2 * sizeof(int))) != hipSuccess) return done(e);
     if (n_steps) hipLaunchKernelGGL(first_visit_kernel, dim3(4096), dim3(256), 0, 0, d_step_node, n_steps, n_nodes, d_first, d_bad);
+    if ((e = hipMemcpy(bad_out, d_bad, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return done(e);
+    if (*bad_out) return done(hipSuccess);                                 // (the kernels below index by step_node)
     hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, 0, d_ids, n_nodes);
     size_t tmp_bytes = 0;
     e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t *)d_first, (uint64_t *)d_first_sorted, d_ids, d_ids_sorted,
@@ -164,9 +232,35 @@ hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_ste
     e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (uint64_t *)d_first, (uint64_t *)d_first_sorted, d_ids, d_ids_sorted,
                                   (size_t)n_nodes, 0, 64, 0);                 // stable: unvisited nodes stay in index order
     if (e != hipSuccess) return done(e);
+    if (n_steps && d_path_first) {
+        // branches: run heads by pointer jumping along the runs, anchors, roots by pointer jumping along the anchors
+        int *d_changed = d_bad + 1;
+        auto jump_to_fixpoint = [&](uint32_t *&cur, uint32_t *&other) -> hipError_t {
+            for (int round = 0; round < 40; ++round) {
+                hipError_t err = hipMemset(d_changed, 0, sizeof(int));
+                if (err != hipSuccess) return err;
+                hipLaunchKernelGGL(jump_kernel, dim3(2048), dim3(256), 0, 0, cur, other, n_nodes, d_changed);
+                std::swap(cur, other);
+                int changed = 0;
+                if ((err = hipMemcpy(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return err;
+                if (!changed) break;
+            }
+            return hipSuccess;
+        };
+        hipLaunchKernelGGL(run_up_kernel, dim3(2048), dim3(256), 0, 0, d_step_node, d_first, d_path_first, n_paths, n_nodes, d_a);
+        if ((e = jump_to_fixpoint(d_a, d_b)) != hipSuccess) return done(e);                          // d_a = run head of every node
+        hipLaunchKernelGGL(anchor_kernel, dim3(2048), dim3(256), 0, 0, d_step_node, d_first, d_path_first, n_paths, d_a, n_nodes, d_b);
+        std::swap(d_a, d_b);
+        if ((e = jump_to_fixpoint(d_a, d_b)) != hipSuccess) return done(e);                          // d_a = root of every node
+        hipLaunchKernelGGL(branch_key_kernel, dim3(2048), dim3(256), 0, 0, d_first, d_a, d_ids_sorted, n_nodes, d_first_sorted);
+        // stable sort by key of the ids already in first-visit order: (key, first visit)
+        e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (uint64_t *)d_first_sorted, (uint64_t *)d_first, d_ids_sorted, d_ids,
+                                      (size_t)n_nodes, 0, 64, 0);
+        if (e != hipSuccess) return done(e);
+        std::swap(d_ids, d_ids_sorted);
+    }
     hipLaunchKernelGGL(scatter_rank_kernel, dim3(1024), dim3(256), 0, 0, d_ids_sorted, d_perm, n_nodes);
     if ((e = hipGetLastError()) != hipSuccess) return done(e);
-    if ((e = hipMemcpy(bad_out, d_bad, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return done(e);
     return done(hipDeviceSynchronize());
 }
 

@@ -169,20 +169,51 @@ int gfs_shard_quotas(uint64_t updates, const uint64_t *rank_steps, uint32_t worl
     return GFS_OK;
 }
 
-// perm[k] = slot of dense node k: nodes in the order the paths first step on them, unvisited nodes last — the rule
-// gfs_ctx_create applies to ITS graph, here on the whole graph so that all ranks store their replicas alike.
+// perm[k] = slot of dense node k — the rule gfs_ctx_create applies to ITS graph (index_kernels.hip, which explains it), here
+// on the whole graph and on the host, so that all ranks store their replicas alike: nodes in the order the paths first step
+// on them, except that a run of first visits which does not start its path is placed right after the root-run node it
+// branches off (through its chain of anchors); unvisited nodes last, in index order.
 int gfs_shared_node_layout(const gfs_graph_view *g, uint32_t *perm) {
     if (!g || (!perm && g->n_nodes)) return gfs_set_error(GFS_E_ARG, "null argument");
-    const uint64_t N = g->n_nodes;
-    std::fill(perm, perm + N, 0xFFFFFFFFu);
-    uint32_t next = 0;
-    for (uint64_t s = 0; s < g->n_steps; ++s) {
+    const uint64_t N = g->n_nodes, S = g->n_steps;
+    constexpr uint64_t NONE = ~0ull;
+    std::vector<uint64_t> first(N, NONE);
+    for (uint64_t s = 0; s < S; ++s) {
         const uint32_t n = g->step_node[s];
         if (n == GFS_NO_NODE) continue;
         if (n >= N) return gfs_set_error(GFS_E_ARG, "step_node out of range");
-        if (perm[n] == 0xFFFFFFFFu) perm[n] = next++;
+        if (first[n] == NONE) first[n] = s;
     }
-    for (uint64_t k = 0; k < N; ++k) if (perm[k] == 0xFFFFFFFFu) perm[k] = next++;
+    // one pass in step order: the run a first visit belongs to, its anchor, and — anchors are always visited earlier — its root
+    std::vector<uint32_t> root(N);
+    for (uint64_t k = 0; k < N; ++k) root[k] = (uint32_t)k;
+    uint64_t p = 0;                                                    // path of step s
+    bool prev_first = false;                                           // step s-1 was a first visit (same path)
+    uint32_t run_anchor = GFS_NO_NODE;                                 // NO_NODE: the current run is a root run
+    for (uint64_t s = 0; s < S; ++s) {
+        while (p + 1 < g->n_paths && g->path_first_step[p + 1] <= s) ++p;
+        const bool start = g->n_paths && g->path_first_step[p] == s;
+        if (start) prev_first = false;
+        const uint32_t n = g->step_node[s];
+        const bool is_first = n != GFS_NO_NODE && first[n] == s;
+        if (is_first) {
+            if (!prev_first) run_anchor = start ? GFS_NO_NODE : g->step_node[s - 1];          // a new run (its anchor may be absent)
+            if (run_anchor != GFS_NO_NODE) root[n] = root[run_anchor];
+        }
+        prev_first = is_first;
+    }
+    struct Key { uint64_t key, first; uint32_t id; };
+    std::vector<Key> keys(N);
+    for (uint64_t k = 0; k < N; ++k) {
+        const uint64_t f = first[k];
+        keys[k] = {f == NONE ? NONE : (root[k] == k ? 2 * f : 2 * first[root[k]] + 1), f, (uint32_t)k};
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if (a.key != b.key) return a.key < b.key;
+        if (a.first != b.first) return a.first < b.first;
+        return a.id < b.id;
+    });
+    for (uint64_t r = 0; r < N; ++r) perm[keys[r].id] = (uint32_t)r;
     return GFS_OK;
 }
 

@@ -212,3 +212,69 @@ def test_subgraph_keeps_nodes_and_selected_paths():
     assert sub.n_nodes == g.n_nodes and sub.n_paths == 2 and sub.n_steps == counts[1] + counts[4]
     f = g.path_first_step.astype(int)
     assert np.array_equal(sub.step_node[:counts[1]], g.step_node[f[1]:f[2]])
+
+
+def _layout_reference(g):
+    """The node layout rule, restated with plain loops (gfs_shared_node_layout / index_kernels.hip): first-visit path order,
+    except that a run of first visits which does not start its path goes right after the root-run node it branches off."""
+    N, S = g.n_nodes, g.n_steps
+    node = g.step_node
+    starts = set(int(v) for v in g.path_first_step[:-1])
+    first = {}
+    for s in range(S):
+        n = int(node[s])
+        if n != 0xFFFFFFFF and n not in first:
+            first[n] = s
+    root = list(range(N))
+    prev_first, anchor = False, None
+    for s in range(S):
+        if s in starts:
+            prev_first = False
+        n = int(node[s])
+        is_first = n != 0xFFFFFFFF and first[n] == s
+        if is_first:
+            if not prev_first:
+                a = None if s in starts else int(node[s - 1])
+                anchor = None if a in (None, 0xFFFFFFFF) else a
+            if anchor is not None:
+                root[n] = root[anchor]
+        prev_first = is_first
+    big = 1 << 62
+    def key(k):
+        if k not in first:
+            return (big, big, k)
+        return (2 * first[k] if root[k] == k else 2 * first[root[k]] + 1, first[k], k)
+    order = sorted(range(N), key=key)
+    perm = np.empty(N, dtype=np.uint32)
+    perm[order] = np.arange(N, dtype=np.uint32)
+    return perm
+
+
+def test_shared_node_layout_places_branches_where_they_branch_off():
+    from gfasort_amd.distributed import path_order_layout
+    rng = np.random.default_rng(4)
+    n, S = 400, 3000
+    step_node = rng.integers(0, n // 2, S).astype(np.uint32) * 2
+    step_node[rng.integers(0, S, 40)] = 0xFFFFFFFF
+    messy = G.FlatGraph(node_len=np.ones(n, np.uint32), step_node=step_node, step_is_rev=np.zeros(S, np.uint8),
+                        path_first_step=np.array([0, 0, S // 3, S // 3, S], dtype=np.uint64), node_ids=np.arange(1, n + 1, dtype=np.uint64),
+                        path_names=["a", "b", "c", "d"])
+    bub = G.synth_bubbles(3000, 6, 5)
+    for g in (load("lil.gfa"), load("DRB1-3123.gfa"), messy, bub, G.synth_windows(2000, 4, 1000, 3)):
+        perm = path_order_layout(g)
+        assert sorted(perm.tolist()) == list(range(g.n_nodes))
+        assert np.array_equal(perm, _layout_reference(g))
+    # what it is for: consecutive path steps of a bubble graph sit next to each other in the layout — with plain first-visit
+    # order a fifth of them were thousands of slots apart (the alternative alleles)
+    slots = path_order_layout(bub)[bub.step_node].astype(np.int64)
+    inside = np.ones(bub.n_steps - 1, dtype=bool)
+    inside[(bub.path_first_step[1:-1] - 1).astype(np.int64)] = False
+    far = np.abs(np.diff(slots))[inside] > 8
+    assert far.mean() < 0.001, far.mean()
+    # a graph without branches (every path a window of one chain) keeps plain first-visit order
+    w = G.synth_windows(2000, 4, 1000, 3)
+    seen, order = set(), []
+    for v in w.step_node.tolist():
+        if v not in seen:
+            seen.add(v); order.append(v)
+    assert np.array_equal(np.argsort(path_order_layout(w))[:len(order)], np.array(order))
