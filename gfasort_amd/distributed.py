@@ -47,7 +47,7 @@ def shard_quotas(total_updates: int, shard_steps: List[int]) -> List[int]:
 
 
 def path_order_layout(g: FlatGraph) -> np.ndarray:
-    """gfs_shared_node_layout: perm[k] = rank of dense node k in first-visit path order (unvisited nodes last) — the
+    """gfs_shared_node_layout: perm[k] = rank of dense node k in first-visit path order with branches placed where they branch off (unvisited nodes last) — the
     rule libgfasort_hip applies by default, here on the WHOLE graph so that every rank stores its replica alike."""
     from . import hip
     import ctypes as C

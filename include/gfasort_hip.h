@@ -196,7 +196,7 @@ int gfs_path_linear_sgd_layout(const gfs_graph_view *g, const gfs_layout_params 
 /* ---- resident API: graph and positions stay in HBM between calls ---- */
 int   gfs_ctx_create(const gfs_graph_view *g, int device, gfs_ctx **out);
 /* Same, with an explicit internal node layout: node_perm[k] = slot of dense node k in the device
- * position vector (a permutation of 0..n_nodes-1).  NULL = first-visit path order (the default of
+ * position vector (a permutation of 0..n_nodes-1).  NULL = first-visit path order with branches placed where they branch off (the default of
  * gfs_ctx_create).  Ranks of a multi-GPU run that all-reduce the device buffer in place must share
  * one layout.  Upload / download / trace always speak the ABI's dense indices and Layout.coords order;
  * only the raw device pointer (gfs_ctx_positions_device / gfs_ctx_bind_positions) is in device order:
@@ -236,7 +236,7 @@ int   gfs_ctx_trace(gfs_ctx *ctx, gfs_term *out, uint64_t n_terms, uint64_t *cou
  * iterations the replicas are merged.  The collective itself is the CALLER's (RCCL over xGMI: torch.distributed, or
  * ncclAllReduce from the Rust host): the library hands out the device buffer to sum over the ranks and runs the kernels
  * on either side of it.  Only the slots that more than one rank's paths can move are exchanged (all ranks store the
- * positions in one node layout, first-visit path order of the whole graph; a rank's paths touch one span of it);
+ * positions in one node layout, the default layout's rule applied to the whole graph; a rank's paths touch one span of it);
  * gfs_rank_finish_* completes every replica at the end with one full-length f64 sum.                                  */
 #define GFS_MAX_WORLD 64
 
