@@ -409,7 +409,10 @@ static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
     // Round 2: the 1D team kernels run 4 waves per SIMD (128 VGPRs; twin trips keep three blocks of a trip in flight) = 1024
     // lanes per CU; 5 waves (96 VGPRs) spill 58 registers and are slower (profiles/r02/two_partners.log).  The fused launch
     // further bounds the count by the workgroups that are resident at once (setup_common).
-    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1024 : 976);
+    // The layout team kernels live on registers (a twin trip holds six records and three ends' coordinates): built for 2 waves
+    // per SIMD (203 VGPRs, nothing spilled) = 512 lanes per CU they run C4 at 36.6 G updates/s, for 3 waves (28 spilled) at
+    // 29.6-34.9, for 4 (244 spilled) at 18 (profiles/r02/layout_twin.log).
+    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1024 : (team && c->dims >= 2) ? 512 : 976);
     // keep >= 8 updates per stream per batch on small graphs
     const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
     // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight
@@ -463,8 +466,9 @@ static int choose_bundle(gfs_ctx *c, int dims) {
     // profile of the 2-D layout is already below reference streams' at 16: profiles/r02/quality_probe_layout_k.log)
     if (k == 0) k = dims ? 16 : 64;
     c->chain = b == 64 ? k : 1;                       // (nD: team kernels exist for D <= 3; checked above)
-    // Two partners per leader (sgd_device.h Leader): the 1D team kernel at B = 64, unless GFS_F_ONE_PARTNER
-    c->partners = (b == 64 && dims == 0 && !(c->cfg.flags & GFS_F_ONE_PARTNER)) ? 2u : 1u;
+    // Two partners per leader (sgd_device.h Leader): the team kernels at B = 64 (1D; layouts of 2 and 3 dimensions), unless
+    // GFS_F_ONE_PARTNER
+    c->partners = (b == 64 && (dims == 0 || dims == 2 || dims == 3) && !(c->cfg.flags & GFS_F_ONE_PARTNER)) ? 2u : 1u;
     return GFS_OK;
 }
 
@@ -513,6 +517,8 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     rc = choose_bundle(c, dims);
     if (rc) return rc;
     if (!c->cfg.n_streams && c->bundle > 1) c->n_streams = T = auto_stream_count(c, true);   // both counts are multiples of 64
+    if (dims != 0 && c->bundle > 1 && c->block > 256)
+        return fail(GFS_E_ARG, "the layout team kernels are built for workgroups of at most 256 lanes");
     c->atomic_loads = !(c->cfg.flags & GFS_F_PLAIN_LOADS);
     size_t lds = (size_t)c->n_paths * sizeof(uint4) + (size_t)c->zlen_staged * 8;
     c->lds_tables = !(c->cfg.flags & GFS_F_NO_LDS_TABLES) && lds <= 48 * 1024;

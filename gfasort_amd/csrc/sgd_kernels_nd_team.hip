@@ -23,26 +23,57 @@ hipError_t launch_nd_ref(int dims, const KArgs &a, bool lds_tables, bool atomic_
 struct TripND {
     uint64_t sa = 0, sb = 0, first = 0;
     uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0), na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
+    uint4 rc = make_uint4(0, 0, 0, 0), nc = make_uint4(0, 0, 0, 0);    // twin trip: the second partner's step and the step after it
+    // (na, nb, nc: the steps after them, for the node lengths, sgd.rs:1051-1058.  Whole records: loading only their position
+    // words — 8 of the 16 bytes, 10 registers less — made the kernel slower, 32.9 G updates/s on C4.)
+    uint64_t sc = 0;
     uint32_t cnt = 0, flips = 0, k = 1, off = 0;
     bool valid = false, two = false, fused = false;   // fused: both colours of a short-jump trip in this one (fused_trip_nd)
+    bool twin = false;                                // both partners of an aligned leader in this trip (twin_trip_nd)
     int mshift = 0;
 };
 
+// lflips: the run's end flips — bit 0: step a, bit 1: partner 0's step b, bit 2: partner 1's (two partners per leader,
+// sgd_device.h Leader: D >= 2 at B = 64).  tr.flips = bit 0: a, bit 1: the b of the partner this trip works on, bit 2: as drawn.
 template <int B, bool FUSE>
-__device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, uint32_t lflips, int t, uint32_t seg, uint32_t colour,
+__device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, uint32_t lflips, int t, uint32_t seg, uint32_t p, uint32_t colour,
                                                int sub, int q, TripND &tr) {
     constexpr int RUNS = 64 / B;
     const int ll = t * RUNS + q;
-    const uint32_t ok = bcast<B>(L.ok, ll), ra0 = bcast<B>(L.ra0, ll), rb0 = bcast<B>(L.rb0, ll);
-    tr.first = bcast_first<B>(L, ll); tr.cnt = bcast<B>(L.cnt, ll); tr.flips = bcast<B>(lflips, ll);
-    tr.k = (B == 64 && (ok & 1u) && tr.cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, tr.cnt) : 1u;
+    const uint32_t okw = bcast<B>(L.ok, ll);
+    const uint32_t ok = leader_ok(okw, p);
+    const uint32_t ra0 = p ? bcast<B>(L.ra1, ll) : bcast<B>(L.ra0, ll), rb0 = p ? bcast<B>(L.rb1, ll) : bcast<B>(L.rb0, ll);
+    const uint32_t fl = bcast<B>(lflips, ll);
+    tr.first = bcast_first<B>(L, ll); tr.cnt = bcast<B>(L.cnt, ll);
+    tr.flips = (fl & 1u) | (((fl >> (1u + p)) & 1u) << 1) | (fl & 4u);
+    // (the number of trips must not depend on the partner: the trips of a slot go seg by seg, both partners each)
+    tr.k = (B == 64 && ((okw | (okw >> 8)) & 1u) && tr.cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, tr.cnt) : 1u;
     tr.off = B == 64 ? run_offset((uint32_t)B, tr.cnt, tr.k, ra0, rb0, seg) : 0u;
     tr.valid = expand_run<B>(ok, tr.first, tr.cnt, ra0, rb0, sub, colour, tr.off, tr.sa, tr.sb);
     tr.mshift = merged_trip_shift<B>(ok, tr.cnt, ra0, rb0, tr.off);
     const bool two = !(a.dbg & 0x08u) && two_colour<B>(ok, tr.cnt, ra0, rb0);
     tr.two = B == 64 ? two : (__any(two) != 0);
-    tr.ra = make_uint4(0, 0, 0, 0); tr.rb = tr.ra; tr.na = tr.ra; tr.nb = tr.ra;
+    tr.ra = make_uint4(0, 0, 0, 0); tr.rb = tr.ra; tr.na = tr.ra; tr.nb = tr.ra; tr.rc = tr.ra; tr.nc = tr.ra;
     tr.fused = FUSE && B == 64 && tr.mshift != 0 && colour == 0 && two && !(a.dbg & 0x100u);
+    // both partners line-aligned long jumps whose runs are apart: their a-runs are the same blocks, one trip serves both
+    // (sgd_kernels_1d.hip expand_trip has the reasons)
+    tr.twin = FUSE && B == 64 && p == 0u && a.partners == 2u && (okw & 3u) == 3u && ((okw >> 8) & 3u) == 3u && !(a.dbg & 0x04u);
+    if (tr.twin) {
+        const uint32_t rb1 = bcast<B>(L.rb1, ll);
+        const int64_t gap = (int64_t)rb0 - (int64_t)rb1, lim = (int64_t)tr.k * 64 + 64;
+        if (gap < lim && gap > -lim) tr.twin = false;
+        else {
+            tr.sa = tr.first + ra0 + tr.off + (uint32_t)sub;
+            tr.sb = tr.first + rb0 + tr.off + (((uint32_t)sub + ((okw >> 2) & 7u)) & 63u);
+            tr.sc = tr.first + rb1 + tr.off + (((uint32_t)sub + ((okw >> 10) & 7u)) & 63u);
+            tr.valid = true;
+            tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb]; tr.rc = a.step_rec[tr.sc];
+            tr.na = a.step_rec[tr.sa + 1u < a.n_steps ? tr.sa + 1u : tr.sa];
+            tr.nb = a.step_rec[tr.sb + 1u < a.n_steps ? tr.sb + 1u : tr.sb];
+            tr.nc = a.step_rec[tr.sc + 1u < a.n_steps ? tr.sc + 1u : tr.sc];
+            return;
+        }
+    }
     if (tr.fused) {
         // every lane takes its own step of the trip, its partner's record and the two records after them (node lengths)
         const int dst = sub + tr.mshift;
@@ -210,8 +241,113 @@ __device__ __forceinline__ bool fused_trip_nd(const KArgs &a, const TripND &cur,
     return true;
 }
 
+// TWIN trip of the layout kernel (D = 2, 3; B = 64; two partners, both line-aligned long jumps whose runs are apart) — the nD
+// form of K1b's twin_trip (sgd_kernels_1d.hip).  A lane's step a is the a-side of two terms, (a, b) and (a, c); the end of
+// a is the one the run's a-flip selects in both (sgd.rs:1062-1068), the ends of b and c follow their own flips.  One load
+// of a's records and coordinates serves both terms; the second computes on what the first left in the registers; a's end
+// takes ONE add, -(r + r'), b's and c's one each: 3 blocks for 128 updates where two trips take 4.  Returns false when the
+// quota filled before the second term (the pass is dropped in nD, and with it the second partner's term).
+template <int D, bool ATOMIC_LOADS, bool TRACE>
+__device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, const int lane, const uint32_t tid,
+                                             const uint64_t wave_quota, uint64_t &wave_done, uint32_t &done, uint32_t &att, uint32_t &ntr) {
+    const bool fa = (cur.flips & 1u) != 0u, fb = (cur.flips & 2u) != 0u, fc = (cur.flips & 4u) != 0u;     // wave-uniform
+    const uint64_t last_step = cur.first + cur.cnt - 1u;
+    const uint64_t plen = a.path_len[rec_path(cur.ra)];
+    // step a
+    const uint64_t p_a = rec_pos_u64(cur.ra), e_a = cur.sa == last_step ? plen : rec_pos_u64(cur.na);
+    const bool rev_a = (cur.ra.y >> 31) != 0;
+    const double pos_a = (double)p_a + (fa ? (double)(e_a - p_a) : 0.0);              // sgd.rs:1047,1062-1064
+    const bool end_a = fa ? !rev_a : rev_a;
+    const uint32_t node = cur.ra.x;
+    const uint64_t idx_a = (uint64_t)node * 2u + (end_a ? 1u : 0u);
+    double *ptr_a = coord_ptr<D>(a, node == 0xFFFFFFFFu ? 0u : node, end_a);
+    double ca[D], acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { ca[d] = 0.0; acc[d] = 0.0; }
+    if (node != 0xFFFFFFFFu) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) ca[d] = load_pos<ATOMIC_LOADS>(ptr_a + d);
+    }
+    // the two partners: position, end, coordinates (all loaded before any add of the trip)
+    double pos_p[2], cp[2][D]; double *ptr_p[2]; uint64_t idx_p[2]; uint32_t node_p[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint4 &rp = p ? cur.rc : cur.rb; const uint4 &np = p ? cur.nc : cur.nb;
+        const uint64_t sp = p ? cur.sc : cur.sb;
+        const bool fp = p ? fc : fb;
+        const uint64_t p_p = rec_pos_u64(rp), e_p = sp == last_step ? plen : rec_pos_u64(np);
+        const bool rev_p = (rp.y >> 31) != 0;
+        pos_p[p] = (double)p_p + (fp ? (double)(e_p - p_p) : 0.0);                    // :1048,1071-1073
+        const bool end_p = fp ? !rev_p : rev_p;
+        node_p[p] = rp.x;
+        idx_p[p] = (uint64_t)rp.x * 2u + (end_p ? 1u : 0u);
+        ptr_p[p] = coord_ptr<D>(a, rp.x == 0xFFFFFFFFu ? 0u : rp.x, end_p);
+#pragma unroll
+        for (int d = 0; d < D; ++d) cp[p][d] = 0.0;
+        if (rp.x != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) cp[p][d] = load_pos<ATOMIC_LOADS>(ptr_p[p] + d);
+        }
+    }
+    bool touched = false, second = true;
+    double rr[2][D]; int fadd[2] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) rr[p][d] = 0.0;
+        if (!second) continue;                                                         // (wave-uniform)
+        ++att;
+        const double term_dist = fabs(pos_a - pos_p[p]);                               // :1080
+        bool valid = term_dist != 0.0 && node != 0xFFFFFFFFu && node_p[p] != 0xFFFFFFFFu;   // :1081, :1089-1096
+        const unsigned long long vmask = __ballot(valid);
+        const uint64_t remaining = wave_quota - wave_done;
+        const uint32_t nvalid = (uint32_t)__popcll(vmask);
+        if (valid && nvalid > remaining) valid = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull)) < remaining;
+        wave_done += nvalid < remaining ? nvalid : remaining;
+        if (valid) {
+            const double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd_shift<true>(a, cur.ra, p ? cur.rc : cur.rb));   // :1085-1086
+            double deltas[D], mag_sq = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { deltas[d] = ca[d] - cp[p][d]; mag_sq += deltas[d] * deltas[d]; }   // :1108-1113
+            if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }                   // :1116-1119
+            const double mag = sqrt(mag_sq);                                           // :1121
+            const double delta = mu * (mag - term_dist) / 2.0;                         // :1125
+            const double r = delta / mag;                                              // :1142
+            const bool same = idx_a == idx_p[p];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                rr[p][d] = r * deltas[d];
+                if (!same) { ca[d] = ca[d] - rr[p][d]; acc[d] = touched ? acc[d] - rr[p][d] : -rr[p][d]; }   // :1143-1146
+            }
+            if (!same) touched = true;
+            fadd[p] = 1;                                                               // :1147-1148
+            ++done;                                                                    // :1151
+            if (TRACE) {
+                if (ntr < a.trace_per_stream) {
+                    TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                    tt->i = (uint32_t)idx_a; tt->j = (uint32_t)idx_p[p]; tt->d = term_dist;
+                    ++ntr;
+                }
+            }
+        }
+        if (p == 0 && wave_done >= wave_quota) second = false;
+    }
+    if (!(a.dbg & 1u)) {
+        // the adds, re-dealt (issue_adds_regrouped): a's end and b's end, then c's end
+        issue_adds_regrouped<D>(lane, acc, rr[0], (unsigned long long)ptr_a, (unsigned long long)ptr_p[0], (int)touched, fadd[0]);
+        double none[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) none[d] = 0.0;
+        issue_adds_regrouped<D>(lane, rr[1], none, (unsigned long long)ptr_p[1], (unsigned long long)ptr_p[1], fadd[1], 0);
+    }
+    return second;
+}
+
+// (2 waves per SIMD: the kernel needs ~200 VGPRs — a twin trip holds the records of three steps and of the steps after them, the
+// next trip's too, and three ends' coordinates; squeezed into 128 it spilled 244 of them and ran at half the rate.  Hence also
+// the bound on the workgroup size, checked by the host.)
 template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
-__global__ void sgdnd_team_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) sgdnd_team_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
     stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
@@ -235,25 +371,34 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
     while (wave_done < wave_quota && passes < max_passes) {
         ++passes;
         const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
-        const uint32_t lflips = rng.flip() | (rng.flip() << 1);            // the run's end flips: bit 0 = a, bit 1 = b
-        int t = 0; uint32_t seg = 0, colour = 0;
+        uint32_t lflips = rng.flip() | (rng.flip() << 1);                  // the run's end flips: bit 0 = a, bit 1 = b
+        if (a.partners == 2u) lflips |= rng.flip() << 2;                   // bit 2 = the second partner's b
+        int t = 0; uint32_t seg = 0, colour = 0, p = 0;
         TripND cur;
-        expand_trip_nd<B, (D >= 2)>(a, L, lflips, t, seg, colour, sub, q, cur);
+        expand_trip_nd<B, (D >= 2)>(a, L, lflips, t, seg, p, colour, sub, q, cur);
         for (;;) {
-            // the trip after this one (second colour, next trip of the run, next slot): request its records now
-            int t_n = t; uint32_t colour_n = 0u, seg_n = seg;
+            // the trip after this one (second colour, the leader's second partner, next trip of the run, next slot — as in
+            // K1b, sgd_kernels_1d.hip): request its records now
+            int t_n = t; uint32_t colour_n = 0u, seg_n = seg, p_n = p;
             if (colour == 0 && cur.two && !cur.fused) colour_n = 1u;
-            else if (seg + 1u < cur.k) seg_n = seg + 1u;
-            else { t_n = t + 1; seg_n = 0u; }
+            else if (p == 0u && a.partners == 2u && !cur.twin) p_n = 1u;
+            else if (seg + 1u < cur.k) { seg_n = seg + 1u; p_n = 0u; }
+            else { t_n = t + 1; seg_n = 0u; p_n = 0u; }
             const bool have_n = t_n < B;
             TripND nxt;
-            if (have_n) expand_trip_nd<B, (D >= 2)>(a, L, lflips, t_n, seg_n, colour_n, sub, q, nxt);
+            if (have_n) expand_trip_nd<B, (D >= 2)>(a, L, lflips, t_n, seg_n, p_n, colour_n, sub, q, nxt);
+            if (D >= 2 && B == 64 && cur.twin) {
+                if (!twin_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, done, att, ntr)) break;
+                if (wave_done >= wave_quota || !have_n) break;
+                cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
+                continue;
+            }
             if (D >= 2 && B == 64 && cur.fused) {
                 // (a quota that fills between the colours ends the iteration: the pass is dropped in nD, and with it the
                 // second colour — as the generic form drops whatever is left of a pass)
                 if (!fused_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, done, att, ntr)) break;
                 if (wave_done >= wave_quota || !have_n) break;
-                cur = nxt; t = t_n; colour = colour_n; seg = seg_n;
+                cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
                 continue;
             }
             bool valid = cur.valid;
@@ -361,7 +506,7 @@ __global__ void sgdnd_team_kernel(const KArgs a) {
             }
             if (wave_done >= wave_quota) break;                        // what is left of the pass is dropped (no carry-over in nD)
             if (!have_n) break;
-            cur = nxt; t = t_n; colour = colour_n; seg = seg_n;
+            cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
         }
     }
     a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;

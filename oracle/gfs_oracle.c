@@ -956,6 +956,68 @@ static int twin_trip_1d(gfo_state *s, const iter_state *it, const leader_t *ld, 
     return second;
 }
 
+/* Product: sgd_kernels_nd_team.hip twin_trip_nd — the layout form of the twin trip: step a takes the end its run's a-flip
+ * selects in both terms, b and c the ends their own flips select; all coordinates are loaded before any add; the second term
+ * computes on what the first left of a's coordinates; a's end receives ONE add, b's and c's one each.  Coordinates in Layout
+ * order [node][end][dim].  Returns 0 when the quota filled between the terms. */
+static int twin_trip_nd(gfo_state *s, const iter_state *it, const leader_t *ld, uint64_t off, int fa, int fb, int fc,
+                        uint64_t wave_first, uint64_t wave_quota, uint64_t *wave_done, double *c) {
+    const pidx *pi = &s->pi;
+    const uint64_t D = s->D;
+    int ok[2][64], touched[64] = {0}; double td[2][64]; uint64_t ia[64], ip[2][64];
+    double ca[64][GFO_MAX_DIMS], cp[2][64][GFO_MAX_DIMS], acc[64][GFO_MAX_DIMS];
+    for (uint64_t l = 0; l < 64; l++) {
+        const uint64_t sa = ld->first + ld->ra0 + off + l;
+        const uint64_t sp[2] = { ld->first + ld->rb0 + off + ((l + (uint64_t)ld->rot) & 63), ld->first + ld->rb1 + off + ((l + (uint64_t)ld->rot1) & 63) };
+        for (int q = 0; q < 2; q++) {
+            uint64_t i = 0, j = 0;
+            ok[q][l] = nd_prepare(pi, sa, sp[q], fa, q ? fc : fb, &td[q][l], &i, &j);
+            if (ok[q][l]) {
+                ia[l] = i; ip[q][l] = j;
+                for (uint64_t d = 0; d < D; d++) { ca[l][d] = c[i * D + d]; cp[q][l][d] = c[j * D + d]; }
+            }
+        }
+        for (uint64_t d = 0; d < D; d++) acc[l][d] = 0.0;
+    }
+    int second = 1;
+    for (int q = 0; q < 2; q++) {
+        int valid[64]; uint64_t nvalid = 0, rank = 0;
+        for (int l = 0; l < 64; l++) { valid[l] = ok[q][l]; nvalid += (uint64_t)valid[l]; }
+        const uint64_t remaining = wave_quota - *wave_done;
+        for (int l = 0; l < 64; l++) {
+            s->att[wave_first + l]++;
+            if (valid[l] && rank++ >= remaining) valid[l] = 0;
+        }
+        *wave_done += nvalid < remaining ? nvalid : remaining;
+        for (int l = 0; l < 64; l++) {
+            if (!valid[l]) continue;
+            const double mu = fmin(it->eta * (1.0 / td[q][l]), 1.0);                   /* sgd.rs:1085-1086 */
+            double deltas[GFO_MAX_DIMS], mag_sq = 0.0;
+            for (uint64_t d = 0; d < D; d++) { deltas[d] = ca[l][d] - cp[q][l][d]; mag_sq += deltas[d] * deltas[d]; }   /* :1108-1113 */
+            if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }                   /* :1116-1119 */
+            const double mag = sqrt(mag_sq);                                           /* :1121 */
+            const double r = (mu * (mag - td[q][l]) / 2.0) / mag;                      /* :1125, :1142 */
+            const int same = ia[l] == ip[q][l];
+            for (uint64_t d = 0; d < D; d++) {
+                const double r_d = r * deltas[d];
+                if (!same) { ca[l][d] = ca[l][d] - r_d; acc[l][d] = touched[l] ? acc[l][d] - r_d : -r_d; }   /* :1143-1146 */
+                c[ip[q][l] * D + d] = c[ip[q][l] * D + d] + r_d;                       /* :1147-1148 */
+            }
+            if (!same) touched[l] = 1;
+            const uint64_t tg = wave_first + (uint64_t)l;
+            s->done[tg]++;                                                             /* :1151 */
+            if (s->trace && s->ntr[tg] < s->trace_per_stream) {
+                gfo_term *tr = &s->trace[tg * s->trace_per_stream + s->ntr[tg]++];
+                tr->i = (uint32_t)ia[l]; tr->j = (uint32_t)ip[q][l]; tr->d_ij = td[q][l];
+            }
+        }
+        if (q == 0 && *wave_done >= wave_quota) { second = 0; break; }
+    }
+    for (int l = 0; l < 64; l++)
+        if (touched[l]) for (uint64_t d = 0; d < D; d++) c[ia[l] * D + d] = c[ia[l] * D + d] + acc[l][d];
+    return second;
+}
+
 /* Team semantics of the product (sgd1d_team_kernel): per wave of 64 streams, a PASS samples one
  * leader per stream; B TRIPS then expand the 64 leaders as 64/B runs of B lanes (trip t, run q
  * uses leader t*(64/B)+q).  Wave-level quota with a rank cut-off.  1D: the trips of a pass left over when
@@ -985,7 +1047,7 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
             s->lead_p = (uint8_t *)calloc(T / 64, 1);
         }
         leader_t *L = s->lead + wave_first;
-        int lead_fa[64] = {0}, lead_fb[64] = {0};
+        int lead_fa[64] = {0}, lead_fb[64] = {0}, lead_fc[64] = {0};
         while (wave_done < wave_quota && passes < max_passes) {
             if (!carry || s->lead_left[w] == 0 || s->lead_cool[w] != (uint8_t)it.cooling) {
                 passes++;
@@ -994,6 +1056,7 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                     if (s->D) {                                        /* nD: the run's two end flips, drawn by the leader's stream */
                         lead_fa[l] = (int)flip(s->rng + 4 * (wave_first + l));
                         lead_fb[l] = (int)flip(s->rng + 4 * (wave_first + l));
+                        if (s->partners == 2) lead_fc[l] = (int)flip(s->rng + 4 * (wave_first + l));   /* the second partner's b */
                     }
                 }
                 s->lead_left[w] = (uint8_t)B; s->lead_cool[w] = (uint8_t)it.cooling; s->lead_colour[w] = 0; s->lead_seg[w] = 0;
@@ -1025,11 +1088,12 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                 /* (not when the two partner runs overlap or touch: the wave would read, as one partner's positions, what it
                  * has only just added as the other's) */
                 const int64_t pgap = (int64_t)L[t].rb0 - (int64_t)L[t].rb1, plim = (int64_t)ktrips * 64 + 64;
-                if (s->D == 0 && RUNS == 1 && more_partners && !s->no_twin_trip && L[t].ok && L[t].aligned && L[t].ok1 && L[t].aligned1 &&
+                if (s->D != 1 && RUNS == 1 && more_partners && !s->no_twin_trip && L[t].ok && L[t].aligned && L[t].ok1 && L[t].aligned1 &&
                     (pgap >= plim || pgap <= -plim)) {
-                    /* both partners in one trip (product: twin_trip) */
-                    if (!twin_trip_1d(s, &it, &L[t], seg * B, wave_first, wave_quota, &wave_done, x))
-                        s->lead_p[w] = 1;                               /* quota filled between the partners */
+                    /* both partners in one trip (product: twin_trip / twin_trip_nd) */
+                    const int second = s->D ? twin_trip_nd(s, &it, &L[t], seg * B, lead_fa[t], lead_fb[t], lead_fc[t], wave_first, wave_quota, &wave_done, x)
+                                            : twin_trip_1d(s, &it, &L[t], seg * B, wave_first, wave_quota, &wave_done, x);
+                    if (!second) s->lead_p[w] = 1;                      /* quota filled between the partners */
                     else GFO_ADVANCE(1);
                     continue;
                 }
@@ -1083,7 +1147,7 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                             /* nD: every lane of a run uses the end flips its leader drew (sgd.rs:1062,1071);
                              * probe the term without applying it (:1080) */
                             flips_a[l] = lead_fa[t * RUNS + qq];
-                            flips_b[l] = lead_fb[t * RUNS + qq];
+                            flips_b[l] = pp ? lead_fc[t * RUNS + qq] : lead_fb[t * RUNS + qq];
                             if (!nd_term_ok(pi, sa[l], sb[l], flips_a[l], flips_b[l])) continue;
                         } else {
                             double td = fabs((double)pi->rec[sa[l]].pos - (double)pi->rec[sb[l]].pos);

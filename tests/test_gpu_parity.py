@@ -281,8 +281,9 @@ def _mirror_chain(B, dims=0):
 
 
 def _mirror_partners(B, dims=0):
-    """The product's partner draws per leader: two in the 1D team kernel at B = 64 (unless GFS_F_ONE_PARTNER), else one."""
-    return 2 if B == 64 and dims == 0 else 1
+    """The product's partner draws per leader: two in the team kernels at B = 64 — 1D and layouts of 2 and 3 dimensions —
+    unless GFS_F_ONE_PARTNER, else one."""
+    return 2 if B == 64 and dims in (0, 2, 3) else 1
 
 
 
@@ -376,7 +377,8 @@ def test_bundled_nd_sampler_trace_matches_oracle_mirror(B, dims):
     og, op = oracle_graph(g), oracle_params(p)
     c0 = gaussian_init(g, dims, 11)
     c_ref = c0.copy()
-    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g), chain=_mirror_chain(B, dims))
+    st_o = O.State(og, op, dims=dims, n_streams=T, trace_per_stream=K, bundle=B, node_slots=_node_slots(g), chain=_mirror_chain(B, dims),
+                   partners=_mirror_partners(B, dims))
     st_o.run(c_ref)
     so = st_o.stats()
     ctx = hip.Context(g)
@@ -1008,10 +1010,12 @@ def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(graph, fused,
     assert np.array_equal(x.view(np.uint64), x_ref.view(np.uint64))
 
 
+@pytest.mark.parametrize("partners,twin", [(2, True), (2, False), (1, True)])
 @pytest.mark.parametrize("dims", [2, 3])
-def test_layout_team_kernel_single_wave_coords_equal_the_oracle_mirror(dims):
-    """The same for the layout kernels: one wave of sgdnd_team_kernel (end planes, one pair of end flips per run,
-    lane-regrouped adds) against the oracle's sequential mirror, coordinates bit for bit."""
+def test_layout_team_kernel_single_wave_coords_equal_the_oracle_mirror(dims, partners, twin):
+    """The same for the layout kernels: one wave of sgdnd_team_kernel (end planes, one set of end flips per run, two partners
+    per leader with twin trips — or as two trips, or one partner —, lane-regrouped adds) against the oracle's sequential
+    mirror, coordinates bit for bit."""
     g = G.synth_windows(40_000, 8, 20_000, 12)
     p = P.LayoutSGDParams.from_graph(g, dims, 1)
     p.iter_max = 6
@@ -1019,11 +1023,13 @@ def test_layout_team_kernel_single_wave_coords_equal_the_oracle_mirror(dims):
     og, op = oracle_graph(g), oracle_params(p)
     c0 = gaussian_init(g, dims, 5)
     c_ref = c0.copy()
-    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64, dims))
+    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64, dims),
+                   partners=partners, twin_trip=twin)
     st_o.run(c_ref)
     so = st_o.stats()
     ctx = hip.Context(g)
-    ctx.setup_nd(p, hip.make_config(n_streams=64, flags=hip.F_BUNDLE(64)))
+    ctx.setup_nd(p, hip.make_config(n_streams=64, flags=hip.F_BUNDLE(64) | (0 if partners == 2 else hip.F_ONE_PARTNER) |
+                                    (0 if twin else hip.F_DBG_NO_TWIN_TRIP)))
     ctx.upload(c0)
     ctx.run()
     hst = ctx.stats()
