@@ -466,6 +466,11 @@ def main():
             "config": {"workload": workload,
                        "term_updates_per_step": M, "n_streams_per_gpu": int(st1.n_streams),
                        "sampling_bundle": int(st1.bundle), "run_trips": int(st1.run_trips),
+                       "sampler": ("library default: runs of 64 consecutive steps x run_trips trips per sampled step a, two independent "
+                                   "partner draws per a (GFS_F_ONE_PARTNER: one), the waves of a fused launch drawing each iteration's "
+                                   "updates from a shared pool — a departure from the reference's independent terms, see DESIGN.md 3 "
+                                   "and the quality / bubbles legs") if int(st1.bundle) == 64 and not (args.flags & 0x30) else
+                                  "as selected by --flags",
                        "untimed_priming_launch": None if args.no_priming else
                        f"after the {args.warmup} warm-up steps, the {args.steps} steps of the timed region once, untimed, from the "
                        "same start (first-dispatch latency of the kernel function, ~0.12 ms, is not kernel time)",
