@@ -449,8 +449,9 @@ __device__ __forceinline__ uint64_t wave_quota_of(const KArgs &a, uint32_t tid) 
     return wq;
 }
 
-// (5 waves per SIMD: 96 VGPRs and a few spilled registers instead of 123 — the kernel waits on memory 68 % of its
-// cycles, and a fifth wave per SIMD = 1 280 lanes per CU is worth +3 % on C3, 77.5 -> 80.0 G updates/s)
+// (4 waves per SIMD = 128 VGPRs: a twin trip keeps three blocks in flight and the next trip's records are on their way; built
+// for 5 waves — 96 VGPRs — the kernel spills 58 registers and is slower: 88.5 against 91.5 G updates/s on C3 with round 1's
+// launch, profiles/r02/two_partners.log.  Before the twin trips a fifth wave was worth +3 %.)
 template <int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
