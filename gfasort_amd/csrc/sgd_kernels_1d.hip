@@ -126,10 +126,12 @@ __device__ __forceinline__ void expand_trip(const KArgs &a, const Leader &L, int
     tr.twin = B == 64 && p == 0u && a.partners == 2u && (okw & 3u) == 3u && ((okw >> 8) & 3u) == 3u && !(a.dbg & 0x04u);
     const uint32_t rb1 = bcast<B>(L.rb1, ll);
     if (tr.twin) {
-        // ... unless the two partner runs overlap or touch: the wave would read, as one partner's positions, what it has only
-        // just added as the other's (no-return atomics are posted).  With such leaders as twin trips the 525k-node bubble
-        // graph lost a quarter of its precision at path distance 1 (profiles/r02/two_partners.log).
-        const int64_t gap = (int64_t)rb0 - (int64_t)rb1, lim = (int64_t)tr.k * 64 + 64;
+        // ... unless a block of one partner run lies within two trips of the other's (|gap| < 192 steps): the wave would read, as
+        // one partner's positions, what it has only just added as the other's — in the same trip from the very snapshot the
+        // add was computed from (no-return atomics are posted).  Partner runs further apart may overlap as runs: their common
+        // nodes are then read two or more trips after they were added to.  (With round 1's free-running launch such leaders as
+        // twin trips cost the 525k-node bubble graph a quarter of its precision at path distance 1, profiles/r02/two_partners.log.)
+        const int64_t gap = (int64_t)rb0 - (int64_t)rb1, lim = 192;
         if (gap < lim && gap > -lim) tr.twin = false;
     }
     if (tr.twin) {

@@ -55,12 +55,12 @@ __device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, 
     tr.two = B == 64 ? two : (__any(two) != 0);
     tr.ra = make_uint4(0, 0, 0, 0); tr.rb = tr.ra; tr.na = tr.ra; tr.nb = tr.ra; tr.rc = tr.ra; tr.nc = tr.ra;
     tr.fused = FUSE && B == 64 && tr.mshift != 0 && colour == 0 && two && !(a.dbg & 0x100u);
-    // both partners line-aligned long jumps whose runs are apart: their a-runs are the same blocks, one trip serves both
+    // both partners line-aligned long jumps whose blocks keep two trips apart: their a-runs are the same blocks, one trip serves both
     // (sgd_kernels_1d.hip expand_trip has the reasons)
     tr.twin = FUSE && B == 64 && p == 0u && a.partners == 2u && (okw & 3u) == 3u && ((okw >> 8) & 3u) == 3u && !(a.dbg & 0x04u);
     if (tr.twin) {
         const uint32_t rb1 = bcast<B>(L.rb1, ll);
-        const int64_t gap = (int64_t)rb0 - (int64_t)rb1, lim = (int64_t)tr.k * 64 + 64;
+        const int64_t gap = (int64_t)rb0 - (int64_t)rb1, lim = 192;
         if (gap < lim && gap > -lim) tr.twin = false;
         else {
             tr.sa = tr.first + ra0 + tr.off + (uint32_t)sub;
@@ -241,7 +241,7 @@ __device__ __forceinline__ bool fused_trip_nd(const KArgs &a, const TripND &cur,
     return true;
 }
 
-// TWIN trip of the layout kernel (D = 2, 3; B = 64; two partners, both line-aligned long jumps whose runs are apart) — the nD
+// TWIN trip of the layout kernel (D = 2, 3; B = 64; two partners, both line-aligned long jumps whose blocks keep two trips apart) — the nD
 // form of K1b's twin_trip (sgd_kernels_1d.hip).  A lane's step a is the a-side of two terms, (a, b) and (a, c); the end of
 // a is the one the run's a-flip selects in both (sgd.rs:1062-1068), the ends of b and c follow their own flips.  One load
 // of a's records and coordinates serves both terms; the second computes on what the first left in the registers; a's end

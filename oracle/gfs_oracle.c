@@ -1085,9 +1085,9 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                     if (more_partners && !(skip_partner)) s->lead_p[w] = 1; \
                     else if (seg + 1 < ktrips) { s->lead_seg[w] = (uint8_t)(seg + 1); s->lead_p[w] = 0; } \
                     else { s->lead_seg[w] = 0; s->lead_p[w] = 0; s->lead_left[w]--; } } while (0)
-                /* (not when the two partner runs overlap or touch: the wave would read, as one partner's positions, what it
-                 * has only just added as the other's) */
-                const int64_t pgap = (int64_t)L[t].rb0 - (int64_t)L[t].rb1, plim = (int64_t)ktrips * 64 + 64;
+                /* (not when a block of one partner run lies within two trips of the other's: the wave would read, as one
+                 * partner's positions, what it has only just added as the other's) */
+                const int64_t pgap = (int64_t)L[t].rb0 - (int64_t)L[t].rb1, plim = 192;
                 if (s->D != 1 && RUNS == 1 && more_partners && !s->no_twin_trip && L[t].ok && L[t].aligned && L[t].ok1 && L[t].aligned1 &&
                     (pgap >= plim || pgap <= -plim)) {
                     /* both partners in one trip (product: twin_trip / twin_trip_nd) */
