@@ -3,7 +3,9 @@
 // The collective here is a host-staged sum behind a barrier (all ranks share device 0 on a one-GPU box; RCCL refuses two
 // ranks on one device): what is under test is gfs_rank_create / gfs_rank_run / the exchange of the shared slots / the
 // final completion through the callback path — not a collective library.
-//   usage: multi_rank_selftest [ranks = 2] [nodes = 60000] [paths = 24] [window = 6000] [dims = 0] [merge_every = 1]
+//   usage: multi_rank_selftest [ranks = 2] [nodes = 60000] [paths = 24] [window = 6000] [dims = 0] [merge_every = 1] [unvisited = 0]
+// unvisited: that many extra nodes no path steps on (dense indices nodes .. nodes + unvisited - 1): no rank's span covers them, and
+// they must end where they started on every replica (sgd.rs:286-294), not at the 0 a sum of "what I own" with no owner gives.
 // Prints "ok ..." and exits 0 when every rank ends with the same positions and (dims = 0) the chain sorts exactly.
 #include <hip/hip_runtime.h>
 
@@ -80,9 +82,10 @@ int main(int argc, char **argv) {
     const uint64_t N = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 60000, P = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 24,
                    W = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 6000, D = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : 0;
     const uint32_t merge_every = argc > 6 ? (uint32_t)std::atoi(argv[6]) : 1;
+    const uint64_t U = argc > 7 ? std::strtoull(argv[7], nullptr, 10) : 0, NT = N + U;
     if (gfs_device_count() < 1) { std::fprintf(stderr, "no HIP device\n"); return 2; }
     // windows(N, P, W): a chain of N nodes, path p covers nodes o_p .. o_p + W - 1; nodes in block-shuffled input order
-    std::vector<uint32_t> order(N), inv(N), node_len(N), step_node;
+    std::vector<uint32_t> order(N), inv(N), node_len(NT), step_node;
     std::iota(order.begin(), order.end(), 0u);
     uint64_t s1 = 11, s2 = 12;
     for (uint64_t b = 0; b < N; b += 64) {
@@ -90,7 +93,7 @@ int main(int argc, char **argv) {
         for (uint64_t k = e - 1; k > b; --k) std::swap(order[k], order[b + splitmix(s1) % (k - b + 1)]);
     }
     for (uint64_t k = 0; k < N; ++k) inv[order[k]] = (uint32_t)k;              // chain node c sits at dense index inv[c]
-    for (uint64_t k = 0; k < N; ++k) node_len[k] = 1 + (uint32_t)(splitmix(s2) % 16);
+    for (uint64_t k = 0; k < NT; ++k) node_len[k] = 1 + (uint32_t)(splitmix(s2) % 16);
     std::vector<uint64_t> first(1, 0);
     for (uint64_t p = 0; p < P; ++p) {
         const uint64_t o = P > 1 ? p * (N - W) / (P - 1) : 0;
@@ -98,7 +101,7 @@ int main(int argc, char **argv) {
         first.push_back(step_node.size());
     }
     std::vector<uint8_t> rev(step_node.size(), 0);
-    gfs_graph_view g{N, step_node.size(), P, node_len.data(), step_node.data(), rev.data(), first.data()};
+    gfs_graph_view g{NT, step_node.size(), P, node_len.data(), step_node.data(), rev.data(), first.data()};
     gfs_sgd_params prm{};
     prm.iter_max = D ? 30 : 100; prm.min_term_updates = (D ? 10 : 1) * step_node.size(); prm.eps = 0.01; prm.eta_max = (double)W * (double)W;
     prm.theta = 0.99; prm.space = D ? W : W * 17; prm.space_max = D ? 1000 : 100; prm.space_quantization_step = 100; prm.cooling_start = 0.5;
@@ -116,7 +119,7 @@ int main(int argc, char **argv) {
         RankUser user{&sh, r};
         int e = gfs_rank_create(&g, &prm, D, &cfg, &rk);
         if (e < 0) { std::fprintf(stderr, "rank %d create: %s\n", r, gfs_last_error()); rc[r] = e; return; }
-        const uint64_t len = D ? N * 2 * D : N;
+        const uint64_t len = D ? NT * 2 * D : NT;
         std::vector<double> x(len, 0.0);
         if (D) {
             gfs_init_layout(&g, D, prm.seed, x.data());
@@ -136,10 +139,17 @@ int main(int argc, char **argv) {
     uint64_t quota = 0;
     for (int r = 0; r < R; ++r) quota += info[r].quota;
     if (quota != prm.min_term_updates) { std::fprintf(stderr, "FAIL: quotas sum to %llu, not %llu\n", (unsigned long long)quota, (unsigned long long)prm.min_term_updates); return 1; }
+    if (U) {
+        std::vector<double> x0(D ? NT * 2 * D : NT, 0.0);
+        if (D) gfs_init_layout(&g, D, prm.seed, x0.data()); else gfs_init_positions(&g, x0.data());
+        const uint64_t w = D ? 2 * D : 1;
+        for (uint64_t k = N * w; k < NT * w; ++k)
+            if (result[0][k] != x0[k]) { std::fprintf(stderr, "FAIL: unvisited node %llu moved from %g to %g\n", (unsigned long long)(k / w), x0[k], result[0][k]); return 1; }
+    }
     uint64_t inversions = 0;
     if (D == 0) {
         std::vector<uint64_t> ord(N);
-        gfs_sort_order(result[0].data(), N, ord.data());
+        gfs_sort_order(result[0].data(), N, ord.data());                       // (the visited nodes: the chain)
         uint64_t up = 0, down = 0;
         for (uint64_t k = 1; k < N; ++k) { const int64_t d = (int64_t)order[ord[k]] - (int64_t)order[ord[k - 1]]; up += d != 1; down += d != -1; }
         inversions = std::min(up, down);
@@ -147,8 +157,8 @@ int main(int argc, char **argv) {
     } else {
         for (double v : result[0]) if (!(v == v)) { std::fprintf(stderr, "FAIL: NaN\n"); return 1; }
     }
-    std::printf("ok ranks %d nodes %llu paths %llu dims %llu merge_every %u: replicas identical, %s; shared slots %llu of %llu, "
-                "%llu collectives, %.1f MB through the callback\n", R, (unsigned long long)N, (unsigned long long)P, (unsigned long long)D, merge_every,
+    std::printf("ok ranks %d nodes %llu paths %llu dims %llu merge_every %u unvisited %llu: replicas identical, %s; shared slots %llu of %llu, "
+                "%llu collectives, %.1f MB through the callback\n", R, (unsigned long long)N, (unsigned long long)P, (unsigned long long)D, merge_every, (unsigned long long)U,
                 D ? "finite" : "exact chain order", (unsigned long long)info[0].shared_slots, (unsigned long long)N,
                 (unsigned long long)sh.collectives, (double)sh.bytes / 1e6);
     return 0;

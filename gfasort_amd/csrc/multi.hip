@@ -220,7 +220,8 @@ int gfs_shared_node_layout(const gfs_graph_view *g, uint32_t *perm) {
 // Spans and what must be exchanged.  span_lo/hi[r]: the slots [lo, hi) rank r's multi-step paths touch (lo == hi: none).
 // seg_lo/hi[0..*n_seg): the maximal slot intervals covered by two or more spans, ascending (at most world - 1 of them...
 // at most 2*world entries are ever written).  own_lo/hi/own_rank[0..*n_own): maximal intervals with their designated
-// owner = the lowest rank whose span covers them (uncovered slots belong to nobody and never move); at most 2*world.
+// owner = the lowest rank whose span covers them; slots no span covers (they never move) belong to rank 0, so that the
+// intervals tile [0, n_nodes): at most 2*world + 1 entries, the arrays must hold 2*world + 2.
 int gfs_exchange_plan(const gfs_graph_view *g, const uint32_t *perm, const uint32_t *path_owner, uint32_t world,
                       uint64_t *span_lo, uint64_t *span_hi, uint64_t *seg_lo, uint64_t *seg_hi, uint32_t *n_seg,
                       uint64_t *own_lo, uint64_t *own_hi, uint32_t *own_rank, uint32_t *n_own) {
@@ -270,7 +271,24 @@ int gfs_exchange_plan(const gfs_graph_view *g, const uint32_t *perm, const uint3
         }
     }
     *n_seg = ns;
-    if (n_own) *n_own = no;
+    if (own_lo && own_hi && own_rank && n_own) {
+        // Slots no span covers — nodes no path visits, nodes only one-step paths step on, gaps between spans — never move,
+        // but gfs_rank_finish_* rebuilds every replica as the SUM of what the ranks own: a slot nobody owned came out as 0
+        // where a world == 1 run (and the reference, sgd.rs:286-294) leaves the start position.  Rank 0 owns them, so that
+        // the own_* intervals tile [0, n_nodes): at most 2*world + 1 of them.
+        std::vector<uint64_t> lo2, hi2; std::vector<uint32_t> rk2;
+        auto push = [&](uint64_t l, uint64_t h, uint32_t r) {
+            if (l >= h) return;
+            if (!lo2.empty() && hi2.back() == l && rk2.back() == r) hi2.back() = h;
+            else { lo2.push_back(l); hi2.push_back(h); rk2.push_back(r); }
+        };
+        uint64_t at = 0;
+        for (uint32_t k = 0; k < no; ++k) { push(at, own_lo[k], 0u); push(own_lo[k], own_hi[k], own_rank[k]); at = own_hi[k]; }
+        push(at, g->n_nodes, 0u);
+        no = (uint32_t)lo2.size();
+        for (uint32_t k = 0; k < no; ++k) { own_lo[k] = lo2[k]; own_hi[k] = hi2[k]; own_rank[k] = rk2[k]; }
+        *n_own = no;
+    }
     return GFS_OK;
 }
 
@@ -336,8 +354,8 @@ int gfs_rank_create(const gfs_graph_view *g, const gfs_sgd_params *p, uint64_t d
     if ((rc = gfs_shard_quotas(p->min_term_updates, r->rank_steps.data(), W, r->quotas.data()))) return bail(rc);
     std::vector<uint32_t> perm(std::max<uint64_t>(g->n_nodes, 1));
     const bool multi = W > 1;
-    std::vector<uint64_t> seg_lo(2 * W), seg_hi(2 * W), own_lo(2 * W), own_hi(2 * W);
-    std::vector<uint32_t> own_rank(2 * W);
+    std::vector<uint64_t> seg_lo(2 * W), seg_hi(2 * W), own_lo(2 * W + 2), own_hi(2 * W + 2);
+    std::vector<uint32_t> own_rank(2 * W + 2);
     uint32_t n_seg = 0, n_own = 0;
     if (multi) {
         if ((rc = gfs_shared_node_layout(g, perm.data()))) return bail(rc);

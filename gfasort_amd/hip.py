@@ -294,8 +294,8 @@ class ShardPlan:
         self.perm = self.perm[:g.n_nodes]
         self.span_lo, self.span_hi = np.zeros(world, dtype=np.uint64), np.zeros(world, dtype=np.uint64)
         seg_lo, seg_hi = np.zeros(2 * world, dtype=np.uint64), np.zeros(2 * world, dtype=np.uint64)
-        own_lo, own_hi = np.zeros(2 * world, dtype=np.uint64), np.zeros(2 * world, dtype=np.uint64)
-        own_rank = np.zeros(2 * world, dtype=np.uint32)
+        own_lo, own_hi = np.zeros(2 * world + 2, dtype=np.uint64), np.zeros(2 * world + 2, dtype=np.uint64)
+        own_rank = np.zeros(2 * world + 2, dtype=np.uint32)
         n_seg, n_own = C.c_uint32(0), C.c_uint32(0)
         po = np.ascontiguousarray(self.path_owner) if g.n_paths else np.zeros(1, dtype=np.uint32)
         pm = np.ascontiguousarray(self.perm) if g.n_nodes else np.zeros(1, dtype=np.uint32)

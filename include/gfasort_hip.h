@@ -275,7 +275,9 @@ int gfs_shared_node_layout(const gfs_graph_view *g, uint32_t *perm /*[n_nodes]*/
 int gfs_exchange_plan(const gfs_graph_view *g, const uint32_t *perm, const uint32_t *path_owner, uint32_t world,
                       uint64_t *span_lo, uint64_t *span_hi /*[world]*/,
                       uint64_t *seg_lo, uint64_t *seg_hi /*[2*world]*/, uint32_t *n_seg,
-                      uint64_t *own_lo, uint64_t *own_hi, uint32_t *own_rank /*[2*world] or NULL*/, uint32_t *n_own);
+                      uint64_t *own_lo, uint64_t *own_hi, uint32_t *own_rank /*[2*world+2] or NULL*/, uint32_t *n_own);
+/* (own_*: every slot has exactly one designated owner — the lowest rank whose span covers it, rank 0 for slots no span covers —
+ * so the intervals tile [0, n_nodes) and gfs_rank_finish_* leaves untouched nodes at their start positions, as sgd.rs:286-294 does) */
 
 /* one rank.  g is the WHOLE graph (every rank derives the same plan from it and keeps only its shard on the device);
  * dims = 0: path_linear_sgd, else path_linear_sgd_layout with that many dimensions.                                  */

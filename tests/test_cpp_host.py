@@ -119,12 +119,14 @@ def test_cli_layout_tsv(bins, tmp_path):
 # ---- the multi-device C ABI from C++: one host thread per rank, gfs_rank_run with a caller-supplied collective ---------
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [["2"], ["4", "60000", "24", "6000", "0", "2"], ["3", "40000", "12", "8000", "2", "1"],
-                                  ["5", "30000", "3", "12000"]])
+                                  ["5", "30000", "3", "12000"], ["3", "40000", "12", "8000", "0", "1", "500"],
+                                  ["2", "40000", "12", "8000", "2", "1", "300"]])
 def test_multi_rank_selftest_threads_and_callback(args):
     """gfasort_amd/bin/multi_rank_selftest (csrc/host/multi_selftest.cpp): R host threads, each a gfs_rank on device 0,
     the whole schedule through gfs_rank_run with a host-staged all-reduce callback — the shape of a Rust host with one
     thread per GPU.  Replicas identical, quotas sum exactly, the chain sorts exactly (1D); with 5 ranks
-    on 3 paths two ranks are idle and still take part in every collective."""
+    on 3 paths two ranks are idle and still take part in every collective; with unvisited nodes (7th argument) those end
+    where they started on every replica (the final sum of "what I own" must give every slot an owner)."""
     B.build_host()
     out = subprocess.run([B.MULTI_SELFTEST] + args, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr

@@ -165,6 +165,18 @@ def test_a_shard_of_single_step_paths_is_idle():
     g, p, x, quotas, facts = _check_common(name, iters, world, _run(name, iters, world))
     assert quotas == [41, 41, 41, 41, 0] and [f[0] for f in facts] == [0.0, 0.0, 0.0, 0.0, 1.0]
     assert res_shards(name, world)[4] == [4, 5, 6, 7]
+    # nodes 160..199 are on no path at all: no rank's span covers them, and after finish() they must sit where they
+    # started on every replica (sgd.rs:286-294: untouched nodes keep their cumulative-length start) — a finish() that sums
+    # "what I own" with nobody owning them would zero them
+    x0 = O.init_positions(oracle_graph(g))
+    assert np.array_equal(x[160:], x0[160:]) and (x0[160:] > 0).all()
+
+
+def test_two_ranks_leave_unvisited_nodes_where_they_started():
+    name, iters, world = "single_step_shard", 6, 2
+    g, p, x, quotas, facts = _check_common(name, iters, world, _run(name, iters, world))
+    x0 = O.init_positions(oracle_graph(g))
+    assert np.array_equal(x[160:], x0[160:]) and (x0[160:] > 0).all()
 
 
 def test_eight_ranks_windows_exchange_only_the_overlaps():

@@ -170,7 +170,8 @@ def test_shard_paths_balanced_and_complete():
 
 def test_exchange_plan_spans_and_shared_slots():
     """gfs_exchange_plan: windows over a chain — each rank's paths touch one span of the shared layout; only the
-    overlaps are exchanged; every touched slot has exactly one designated owner (the lowest covering rank)."""
+    overlaps are exchanged; every slot has exactly one designated owner (the lowest covering rank; rank 0 for slots no
+    span covers, so that gfs_rank_finish_* leaves untouched nodes where they started — sgd.rs:286-294)."""
     from gfasort_amd import hip
     g = G.synth_windows(10_000, 8, 2_000, 3, shuffle=False)            # path p covers nodes o_p .. o_p + 2000
     plan = hip.ShardPlan(g, 1000, 4)
@@ -190,10 +191,29 @@ def test_exchange_plan_spans_and_shared_slots():
     for lo, hi, r in plan.owned:
         assert (owner[lo:hi] == -1).all()
         owner[lo:hi] = r
-    assert ((owner >= 0) == (cover >= 1)).all()
+    assert (owner >= 0).all()                                            # the intervals tile [0, n_nodes)
+    assert (owner[cover == 0] == 0).all()
     for r in range(4):
-        mine = owner == r
+        mine = (owner == r) & (cover >= 1)
         assert (mine[:int(plan.span_lo[r])] == False).all() and (mine[int(plan.span_hi[r]):] == False).all()
+    # gaps: paths over two far-apart stretches of a chain with unvisited nodes before, between and after them
+    n = 1000
+    steps = [np.arange(100, 300), np.arange(250, 400), np.arange(600, 800), np.arange(700, 900)]
+    counts = [len(v) for v in steps]
+    gg = G.FlatGraph(node_len=np.full(n, 2, dtype=np.uint32), step_node=np.concatenate(steps).astype(np.uint32),
+                     step_is_rev=np.zeros(sum(counts), np.uint8),
+                     path_first_step=np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64),
+                     node_ids=np.arange(1, n + 1, dtype=np.uint64), path_names=[f"p{k}" for k in range(4)])
+    pl = hip.ShardPlan(gg, 750, 4)
+    owner = np.full(n, -1)
+    for lo, hi, r in pl.owned:
+        assert (owner[lo:hi] == -1).all()
+        owner[lo:hi] = r
+    assert (owner >= 0).all()
+    slot_of = pl.perm.astype(int)                                        # visited nodes first, unvisited last
+    unvisited = np.setdiff1d(np.arange(n), np.concatenate(steps))
+    assert (owner[slot_of[unvisited]] == 0).all()
+    assert len(pl.owned) <= 2 * 4 + 1
     whole = hip.ShardPlan(g, 1000, 4, whole_vector=True)
     assert whole.shared == [(0, g.n_nodes)]
 
