@@ -2,7 +2,7 @@
 // context (device mirror of PathIndex + positions + RNG streams) and the one-shot entry points
 // that stand where path_linear_sgd / path_linear_sgd_layout stand in the reference.
 #include "../../include/gfasort_hip.h"
-#include "sgd_device.h"
+#include "sgd_kernel_common.h"
 
 #include <algorithm>
 #include <chrono>
@@ -23,6 +23,10 @@ hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_load
 size_t pool_bytes(uint64_t n_iters);
 hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
                            dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t launch_1d_ref_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
+                               dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t launch_nd_ref_fused(int dims, const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
+                               dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t warm_module_1d();
 hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu);
 hipError_t warm_module_nd();
@@ -551,7 +555,7 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     }
     rc = seed_streams(c);
     if (rc) return rc;
-    if (dims == 0 && c->bundle >= 16 && c->params.iter_max < (1u << 20)) {
+    if (((dims == 0 && c->bundle >= 16) || c->bundle == 1) && c->params.iter_max < (1u << 20)) {
         // the whole schedule's per-iteration constants, for fused launches over consecutive iterations
         std::vector<gfs::IterConsts> all(c->params.iter_max + 1);
         for (uint64_t k = 0; k <= c->params.iter_max; ++k) iter_consts(c, k, all[k]);
@@ -645,6 +649,18 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
         c->path_counts.push_back(cnt);
         if (cnt > 1) c->valid_paths = true;                               // sgd.rs:250-256
         c->max_path_steps = std::max(c->max_path_steps, cnt);
+    }
+    {   // a step record keeps 55 bits of a step's bp position (its top bits carry the crowding exponents): refuse longer paths
+        // instead of truncating them.  Cheap bound first (steps x longest node), the exact sum only where that fails.
+        uint32_t max_len = 0;
+        for (uint64_t k = 0; k < g->n_nodes; ++k) max_len = std::max(max_len, g->node_len[k]);
+        for (uint64_t p = 0; p < g->n_paths; ++p) {
+            const uint64_t b = g->path_first_step[p], e2 = g->path_first_step[p + 1];
+            if ((unsigned __int128)(e2 - b) * max_len < ((unsigned __int128)1 << 55)) continue;
+            unsigned __int128 bp = 0;
+            for (uint64_t s2 = b; s2 < e2; ++s2) { const uint32_t n = g->step_node[s2]; if (n < g->n_nodes) bp += g->node_len[n]; }
+            if (bp >= ((unsigned __int128)1 << 55)) { delete c; return fail(GFS_E_UNSUPPORTED, "a path of 2^55 bp or more"); }
+        }
     }
     // K3 on the device: PathIndex::from_graph (sgd.rs:34-71) — the per-path exclusive prefix sum of
     // node lengths over the steps — written straight into the 16-byte step records
@@ -822,6 +838,8 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.bundle = c->bundle;
     a.chain = c->chain;
     a.partners = c->partners;
+    a.ref_chunk = gfs::REF_CHUNK_PER_LANE;
+    if (const char *e = std::getenv("GFS_DBG_REF_CHUNK")) { const long v = std::atol(e); if (v >= 1 && v <= 4096) a.ref_chunk = (uint32_t)v; }   // probe knob (scripts/ref_fused_probe.py)
     a.n_nodes = (uint32_t)c->n_nodes;
     {   // crowding onset (sgd_device.h crowd_shift): four times the concurrency of an average node
         const uint64_t per = c->n_steps / std::max<uint64_t>(2 * c->n_streams, 1);
@@ -875,16 +893,28 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     return GFS_OK;
 }
 
-// A range of iterations ks[0..n) (each in 0..=iter_max).  On one GPU with the team kernel this is ONE
-// fused launch (sgd1d_team_fused_kernel); otherwise it falls back to one launch per iteration.
+// A range of iterations ks[0..n) (each in 0..=iter_max): ONE fused launch for the 1D team kernel (sgd1d_team_fused_kernel)
+// and for reference streams (sgd1d_fused_kernel, sgdnd_fused_kernel); otherwise one launch per iteration.
 int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stream) {
     if (!c || (!ks && n)) return fail(GFS_E_ARG, "null argument");
     if (!c->configured) return fail(GFS_E_STATE, "context not set up");
     if (!c->valid_paths || c->n_nodes == 0) return GFS_NOTHING_TO_DO;
     for (uint64_t i = 0; i < n; ++i) if (ks[i] > c->params.iter_max) return fail(GFS_E_ARG, "iteration beyond iter_max");
-    const bool can_fuse = c->dims == 0 && c->bundle >= 16 && c->atomic_loads && !c->d_trace && n > 1 && n <= 0xFFFFFFFFull &&
-                          !(c->cfg.flags & GFS_F_NO_FUSE) &&
-                          (c->n_streams + c->block - 1) / c->block <= c->fused_resident_blocks;     // every workgroup resident
+    // One persistent launch for the range where a fused kernel exists: the 1D team kernel at its widest bundles (K1c) and
+    // reference streams in any dimension (K1d / K2d).  The waves of a fused launch draw an iteration's updates from a work
+    // pool (a share per counter beyond 2^31 — 3e10 updates per iteration — cannot be pooled: one launch per iteration
+    // then, unless the diagnostic GFS_F_DBG_FREE_RUNNING asks for round 1's fixed quotas).  The team kernel is only fused
+    // with every workgroup resident — which assumes this context has the device to itself: concurrent streams or a second
+    // rank on the same device can delay a workgroup, harmlessly under pools (a late wave finds the counters exhausted and
+    // leaves), not so with fixed quotas.
+    const uint64_t n_waves = (c->n_streams + 63) / 64;
+    const bool pool_ok = n_waves <= 0xFFFFFFFFull && c->quota_total / gfs::pool_slots((uint32_t)n_waves) < (1ull << 31);
+    const bool free_running = (c->cfg.flags & GFS_F_DBG_FREE_RUNNING) != 0;
+    const bool team_fusable = c->dims == 0 && c->bundle >= 16 && (pool_ok || free_running) &&
+                              (c->n_streams + c->block - 1) / c->block <= c->fused_resident_blocks;   // every workgroup resident
+    const bool ref_fusable = c->bundle == 1 && pool_ok;
+    const bool can_fuse = (team_fusable || ref_fusable) && c->atomic_loads && !c->d_trace && n > 1 && n <= 0xFFFFFFFFull &&
+                          !(c->cfg.flags & GFS_F_NO_FUSE);
     if (!can_fuse) {
         for (uint64_t i = 0; i < n; ++i) { int rc = gfs_ctx_run_iteration(c, ks[i], hip_stream); if (rc) return rc; }
         return GFS_OK;
@@ -924,11 +954,9 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     fill_kargs(c, a);
     iter_consts(c, ks[0], a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
-    // work pools (sgd_kernels_1d.hip): the waves draw an iteration's updates from shared counters, zeroed per launch.
-    // (A share per counter beyond 2^31 — 3e10 updates per iteration — keeps the fixed quotas.)
+    // work pools (sgd_kernels_1d.hip): the waves draw an iteration's updates from shared counters, zeroed per launch
     uint32_t *pool = nullptr;
-    const uint64_t n_waves = c->n_streams / 64;
-    if (!(c->cfg.flags & GFS_F_DBG_FREE_RUNNING) && c->quota_total / std::min<uint64_t>(16, std::max<uint64_t>(n_waves, 1)) < (1ull << 31)) {
+    if (pool_ok && !(free_running && c->bundle > 1)) {
         if (c->pool_cap < n) {
             if (c->d_pool) HIPCHK(hipFree(c->d_pool));
             c->d_pool = nullptr; c->pool_cap = 0;
@@ -942,7 +970,9 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     int rc = next_event_pair(c, ev);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev->first, st));                // (the event pair brackets the kernel alone)
-    hipError_t e = gfs::launch_1d_fused(a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st);
+    hipError_t e = c->bundle > 1 ? gfs::launch_1d_fused(a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st)
+                   : c->dims == 0 ? gfs::launch_1d_ref_fused(a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st)
+                                  : gfs::launch_nd_ref_fused(c->dims, a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st);
     if (e != hipSuccess) return fail(GFS_E_HIP, std::string("fused kernel launch: ") + hipGetErrorString(e));
     HIPCHK(hipEventRecord(ev->second, st));
     c->iterations += n;

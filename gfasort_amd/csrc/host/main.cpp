@@ -29,6 +29,10 @@ static void usage() {
         "                   [--dimensions D] [--layout-out FILE] [--layout-iter N] [--streams N]\n"
         "                   [--io-threads N]   (host threads for GFA text passes; default: available CPUs, <= 16)\n"
         "                   [--bundle auto|1|4|8|16|32|64]   (sampling bundle; 1 = reference streams)\n"
+        "                   [--reference-sampler]   (= --bundle 1: every term sampled independently, as src/sgd.rs:444-497 does;\n"
+        "                                            ~8x slower on large graphs.  The default on graphs of >= 16384 nodes samples RUNS of\n"
+        "                                            terms; on graphs whose haplotypes differ by kilobases it needs a longer schedule\n"
+        "                                            (--iter-max 300) to reach what the reference's sampler reaches, DESIGN.md)\n"
         "Pipeline characters: Y = path-guided SGD sort, L = nD layout (HIP engine).\n"
         "g, s, S, u exist in the reference but are not part of this build.\n";
 }
@@ -50,6 +54,7 @@ static bool parse_args(int argc, char **argv, Args &a) {
         else if (f == "--io-threads") { if (!(v = need(i))) return false; set_io_threads(std::stoull(v)); }
         else if (f == "--streams") { if (!(v = need(i))) return false; a.streams = std::stoull(v); }
         else if (f == "--bundle") { if (!(v = need(i))) return false; a.bundle = std::string(v) == "auto" ? 0u : (unsigned)std::stoul(v); }
+        else if (f == "--reference-sampler") { a.bundle = 1; }
         else if (f == "--hip-flags") { if (!(v = need(i))) return false; a.flags = (uint32_t)std::stoul(v); }
         else if (f == "-h" || f == "--help") { usage(); exit(0); }
         else { std::cerr << "error: unexpected argument '" << f << "'\n"; return false; }

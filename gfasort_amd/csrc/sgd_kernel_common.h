@@ -104,5 +104,60 @@ __device__ __forceinline__ uint32_t merged_trip_base(uint32_t cnt, uint32_t ra0,
     return (uint32_t)base;
 }
 
+// ------------------------------------------------------------------------------------------
+// WORK POOLS of a fused launch (K1c sgd1d_team_fused_kernel explains them; K1d / K2d below use the same counters): an
+// iteration's updates are claimed in chunks from one of up to POOL_SLOTS counters, one 64-B line each.
+constexpr uint32_t POOL_SLOTS = 16, POOL_STRIDE = 16;              // counters per iteration; u32 per 64-B line
+// Counters in use: one per 16 waves, at most POOL_SLOTS.  Several counters exist so that 4 000 waves do not queue on one
+// address; a counter must still be SHARED by many waves — a wave with a counter of its own has a fixed quota again and drifts
+// away from the others in the schedule (a 40-lane last wave beside 15 full ones, each on its own counter, ran 60 % behind and
+// cost DRB1 a fifth of its final stress: 0.39 against 0.33, round 3).
+__host__ __device__ __forceinline__ uint32_t pool_slots(uint32_t n_waves) {
+    const uint32_t s = n_waves / 16u;
+    return s < 1u ? 1u : (s > POOL_SLOTS ? POOL_SLOTS : s);
+}
+
+// K1d / K2d: REFERENCE STREAMS, a range of iterations in ONE persistent launch.  The reference's workers never stop at an
+// iteration boundary — the checker thread switches eta / theta / cooling under them (sgd.rs:366-403) — and they share ONE
+// count of term updates per iteration (sgd.rs:579-583).  One launch per iteration costs a small graph more than its
+// updates do (DRB1: 35 059 updates in 0.1 ms, most of it launch ramp and tail).  Here every wave walks the schedule
+// its[0..n) and claims an iteration's updates from the pool in chunks of REF_CHUNK_PER_LANE per live lane (one returning
+// atomic per wave and chunk, the next claim travelling while the chunk is worked on); a chunk is dealt to the lanes —
+// each an ordinary reference stream — in equal shares.  Every iteration applies exactly min_term_updates updates under
+// its own constants; no wave is more than two chunks from the others.  ONE stream claims every chunk itself, in order,
+// and is bit for bit the per-iteration kernel and the oracle's single stream (tested).
+constexpr uint32_t REF_CHUNK_PER_LANE = 16;
+
+// run(share, max_attempts): the stream's loop for `share` successful updates (ref_run_1d / ref_run_nd)
+template <class Run>
+__device__ __forceinline__ void ref_pooled_walk(KArgs &a, const IterConsts *its, const uint32_t n_iters, uint32_t *pool,
+                                                const uint32_t tid, Run &&run) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_first = tid & ~63u;                                            // < n_streams (caller)
+    const uint32_t nl = a.n_streams - wave_first < 64u ? a.n_streams - wave_first : 64u;   // live lanes of this wave
+    const uint32_t chunk = nl * a.ref_chunk;
+    const uint32_t wave = tid >> 6, n_waves = (a.n_streams + 63u) >> 6;
+    const uint32_t slots = pool_slots(n_waves), slot = wave % slots;
+    const uint64_t total = (uint64_t)a.quota_base * a.n_streams + a.quota_rem;
+    const uint32_t cap = (uint32_t)(total / slots + (slot < total % slots ? 1u : 0u));     // < 2^31 (host-checked)
+    uint32_t k = 0, claim = 0;
+    a.it = its[0];
+    if (lane == 0) claim = __hip_atomic_fetch_add(pool + slot * POOL_STRIDE, chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (k < n_iters) {
+        const uint32_t old = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+        if (old >= cap) {                                                              // this iteration's pool is exhausted
+            if (++k == n_iters) break;
+            a.it = its[k];                                                             // wave-uniform: scalar loads
+            if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, chunk,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, chunk,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t m = cap - old < chunk ? cap - old : chunk;
+        const uint32_t share = lane < nl ? m / nl + (lane < m % nl ? 1u : 0u) : 0u;
+        if (share) run(share, (uint64_t)a.attempt_factor * share + 64u);
+    }
+}
 
 }  // namespace gfs

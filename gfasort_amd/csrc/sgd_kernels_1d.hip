@@ -5,8 +5,72 @@
 namespace gfs {
 
 // ------------------------------------------------------------------------------------------
-// K1: 1D
+// K1: 1D reference streams — one lane = one reference worker thread (sgd.rs:429-590)
 // ------------------------------------------------------------------------------------------
+// Everything of one loop trip that does not depend on the positions: the pair sampler and the rejections of
+// sgd.rs:444-538.  Returns false where the reference `continue`s.
+struct RefTerm1D { uint32_t i, j; int crowd; double term_dist; };
+
+template <bool LDS_TABLES>
+__device__ __forceinline__ bool ref_sample_1d(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng, RefTerm1D &t) {
+    uint4 ra, rb; uint64_t sa, sb; uint32_t cnt, path;
+    if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) return false;
+    t.term_dist = fabs(rec_pos(ra) - rec_pos(rb));                                     // sgd.rs:513
+    if (t.term_dist == 0.0) return false;                                              // :514
+    t.crowd = crowd_shift<false>(a, ra, rb);
+    t.i = ra.x; t.j = rb.x;
+    return t.i != 0xFFFFFFFFu && t.j != 0xFFFFFFFFu;                                   // :525-538
+}
+
+// The worker loop for `quota` successful updates.  Sampling reads no positions, so the NEXT term is sampled — its two
+// dependent record loads — while the position loads of the current one are in flight: a stream is a serial chain of
+// memory round trips and this takes the sampler's two off the chain.  The random numbers are drawn in the reference's
+// order (a term's draws, then the next term's), the terms are applied in the order they were drawn, and no term is
+// sampled that the quota would not apply: one stream is bit for bit the oracle's, with or without the overlap.
+template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__device__ __forceinline__ void ref_run_1d(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng,
+                                           const uint32_t quota, const uint64_t max_att, const uint32_t tid,
+                                           uint32_t &done, uint32_t &att, uint32_t &ntr) {
+    double *x = a.x;
+    uint32_t d = 0; uint64_t t = 0;
+    RefTerm1D cur = {0u, 0u, 0, 0.0}, nxt = {0u, 0u, 0, 0.0};
+    bool have = false;
+    while (d < quota && (have || t < max_att)) {
+        if (!have) {
+            ++t;
+            if (!ref_sample_1d<LDS_TABLES>(a, path_tab, zeta_tab, rng, cur)) continue;
+        }
+        double xi, xj;
+        if (a.dbg & 2u) { xi = (double)cur.i; xj = (double)cur.j; }                    // ablation: no position loads
+        else { xi = load_pos<ATOMIC_LOADS>(x + cur.i); xj = load_pos<ATOMIC_LOADS>(x + cur.j); }   // :541-542
+        have = false;
+        if (d + 1u < quota && t < max_att) { ++t; have = ref_sample_1d<LDS_TABLES>(a, path_tab, zeta_tab, rng, nxt); }
+        const double mu = crowd_scale(fmin(a.it.eta * (1.0 / cur.term_dist), 1.0), cur.crowd);   // :518-520
+        double dx = xi - xj;                                                           // :543
+        if (dx == 0.0) dx = 1e-9;                                                      // :546-548
+        const double mag = fabs(dx);                                                   // :551
+        const double delta = mu * (mag - cur.term_dist) / 2.0;                         // :552
+        const double r = delta / mag;                                                  // :570
+        const double r_x = r * dx;                                                     // :571
+        if (a.dbg & 1u) { asm volatile("" :: "v"(r_x)); }                              // ablation: no atomics
+        else {
+            add_pos(x + cur.i, -r_x);                                                  // :575
+            add_pos(x + cur.j, r_x);                                                   // :576
+        }
+        ++d;                                                                           // :579
+        if (TRACE) {
+            if (ntr < a.trace_per_stream) {
+                TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                tt->i = cur.i; tt->j = cur.j; tt->d = cur.term_dist;
+                ++ntr;
+            }
+        }
+        if (have) cur = nxt;
+    }
+    done += d;
+    att += t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
 template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __global__ void sgd1d_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -22,43 +86,34 @@ __global__ void sgd1d_kernel(const KArgs a) {
         rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid];
         const uint32_t quota = a.quota_base + (tid < a.quota_rem ? 1u : 0u);
         const uint64_t max_att64 = (uint64_t)a.attempt_factor * quota + 1024u;
-        const uint32_t max_att = max_att64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_att64;
+        const uint64_t max_att = max_att64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_att64;
         uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
-        double *x = a.x;
-        while (done < quota && att < max_att) {
-            ++att;
-            uint4 ra, rb; uint64_t sa, sb; uint32_t cnt, path;
-            if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) continue;
-            double term_dist = fabs(rec_pos(ra) - rec_pos(rb));                        // sgd.rs:513
-            if (term_dist == 0.0) continue;                                            // :514
-            double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd_shift<false>(a, ra, rb));                       // :518-520
-            const uint32_t i = ra.x, j = rb.x;
-            if (i == 0xFFFFFFFFu || j == 0xFFFFFFFFu) continue;                        // :525-538
-            double dx;
-            if (a.dbg & 2u) dx = (double)i - (double)j;                                // ablation: no position loads
-            else dx = load_pos<ATOMIC_LOADS>(x + i) - load_pos<ATOMIC_LOADS>(x + j);   // :541-543
-            if (dx == 0.0) dx = 1e-9;                                                  // :546-548
-            double mag = fabs(dx);                                                     // :551
-            double delta = mu * (mag - term_dist) / 2.0;                               // :552
-            double r = delta / mag;                                                    // :570
-            double r_x = r * dx;                                                       // :571
-            if (a.dbg & 1u) { asm volatile("" :: "v"(r_x)); }                          // ablation: no atomics
-            else {
-                add_pos(x + i, -r_x);                                                  // :575
-                add_pos(x + j, r_x);                                                   // :576
-            }
-            ++done;                                                                    // :579
-            if (TRACE) {
-                if (ntr < a.trace_per_stream) {
-                    TraceTerm *t = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
-                    t->i = i; t->j = j; t->d = term_dist;
-                    ++ntr;
-                }
-            }
-        }
+        ref_run_1d<LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, rng, quota, max_att, tid, done, att, ntr);
         a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;
         if (TRACE) a.trace_cnt[tid] = ntr;
     }
+    flush_counters(a, done, att);
+}
+
+// K1d: the same streams, a range of iterations in one persistent launch with work pools (sgd_kernel_common.h
+// ref_pooled_walk).  RNG state stays in registers for the whole schedule.
+template <bool LDS_TABLES>
+__global__ void sgd1d_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters, uint32_t *pool) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a0, smem, path_tab, zeta_tab);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((tid & ~63u) >= a0.n_streams) return;                          // waves without a live lane
+    const bool live = tid < a0.n_streams;
+    const uint64_t T = a0.n_streams;
+    KArgs a = a0;
+    Rng rng = {0, 0, 0, 0};
+    if (live) { rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid]; }
+    uint32_t done = 0, att = 0, ntr = 0;
+    ref_pooled_walk(a, its, n_iters, pool, tid, [&](const uint32_t share, const uint64_t max_att) {
+        ref_run_1d<LDS_TABLES, true, false>(a, path_tab, zeta_tab, rng, share, max_att, tid, done, att, ntr);
+    });
+    if (live) { a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3; }
     flush_counters(a, done, att);
 }
 
@@ -487,14 +542,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_kernel(con
 // sequential mirror gives (profiles/r02/pacing.log).  A counting barrier per iteration (with a lag of 1-6 iterations)
 // restores the precision but leaves the fast waves idle: C3 66-88 G updates/s against 93.
 // Instead an iteration's min_term_updates updates are a POOL that the waves draw from in chunks of TEAM_CHUNK updates
-// (one returning atomic per chunk, on one of up to 16 counters so that the claims do not queue on one address; a wave
+// (one returning atomic per chunk, on one of up to 16 counters — one per 16 waves, sgd_kernel_common.h pool_slots — so that the
+// claims do not queue on one address; a wave
 // claims its next chunk before it works on the current one).  A wave moves on to iteration k + 1 when its counter of
 // iteration k is exhausted: no wave is ever more than two chunks away from the others, nobody waits, and a wave that is
 // slow simply takes fewer chunks — which is the reference's own rule (its workers share one count per iteration).  Every
 // iteration still applies exactly min_term_updates updates with its own eta/theta.  C3: 97.8 G updates/s.
 // (A single wave claims every chunk itself, in order: the kernel with fixed quotas works through its quota in the same
 // chunks, so that one wave is bit for bit the oracle's mirror in both.)
-constexpr uint32_t POOL_SLOTS = 16, POOL_STRIDE = 16;              // counters per iteration; u32 per 64-B line
 template <int B, bool LDS_TABLES, bool ATOMIC_LOADS>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters,
                                                                                    uint32_t *pool) {
@@ -511,7 +566,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_fused_kern
     load_pass(a, tid, ts);
     if (pool) {
         const uint32_t wave = tid >> 6, n_waves = a0.n_streams >> 6;
-        const uint32_t slots = n_waves < POOL_SLOTS ? n_waves : POOL_SLOTS, slot = wave % slots;
+        const uint32_t slots = pool_slots(n_waves), slot = wave % slots;
         const uint64_t total = (uint64_t)a0.quota_base * a0.n_streams + a0.quota_rem;
         const uint32_t cap = (uint32_t)(total / slots + (slot < total % slots ? 1u : 0u));   // < 2^31 (host-checked)
         uint32_t k = 0, claim = 0;
@@ -627,6 +682,14 @@ hipError_t launch_1d_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_i
         case 64: return launch_1d_fused_b<64>(a, d_its, n_iters, lds_tables, pool, grid, block, lds, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// reference streams, fused (K1d); pool: zeroed counters, pool_bytes(n_iters) of them
+hipError_t launch_1d_ref_fused(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
+                               dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (lds_tables) hipLaunchKernelGGL((sgd1d_fused_kernel<true>), grid, block, lds, st, a, d_its, n_iters, pool);
+    else            hipLaunchKernelGGL((sgd1d_fused_kernel<false>), grid, block, 0, st, a, d_its, n_iters, pool);
+    return hipGetLastError();
 }
 
 // The first launch of a kernel function costs the host ~0.1 ms (the runtime materialises the function lazily); a

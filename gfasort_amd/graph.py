@@ -271,6 +271,49 @@ def synth_bubbles(n_sites: int, n_haplotypes: int, seed: int, shuffle: bool = Tr
     )
 
 
+def tile_series(g: FlatGraph, copies: int, shuffle_seed: Optional[int] = None) -> FlatGraph:
+    """A graph `copies` times in series: copy c holds the nodes of g with dense indices (and ids) offset by c * N, and every
+    path of g becomes ONE path that walks copy 0, then copy 1, ... (orientations kept) — a path that traverses g mostly on
+    the reverse strand walks the copies in DESCENDING order instead, as a reverse-strand haplotype of the tiled graph would
+    (DRB1-3123's path 6 is reverse from end to end: walking the copies upwards would put an artificial inversion at every
+    seam, and those 119 seams then carry 60 % of the squared error at path distance 1, profiles/r03/tiled_tail_probe_naive_seams.log).
+    With a real fixture — the
+    reference's tests/data/DRB1-3123.gfa: nested bubbles, 3 096 reverse steps — this gives a graph of real pangenome
+    structure at the sizes where the library's default kernels differ from the reference's sampler.
+    shuffle_seed: emit the S lines block-shuffled (Fisher-Yates inside blocks of 64 nodes) as the synthetic generators do,
+    so that node_order is not the input's order."""
+    N, S, P = g.n_nodes, g.n_steps, g.n_paths
+    first = g.path_first_step.astype(np.int64)
+    counts = np.diff(first)
+    off = (np.arange(copies, dtype=np.int64) * N)
+    steps, revs = [], []
+    for p in range(P):
+        seg = g.step_node[first[p]:first[p + 1]].astype(np.int64)
+        absent = seg == NO_NODE
+        rev_path = seg.size > 0 and 2 * int(g.step_is_rev[first[p]:first[p + 1]].sum()) > seg.size
+        tiled = seg[None, :] + (off[::-1] if rev_path else off)[:, None]
+        tiled[:, absent] = NO_NODE
+        steps.append(tiled.reshape(-1))
+        revs.append(np.tile(g.step_is_rev[first[p]:first[p + 1]], copies))
+    steps0 = np.concatenate(steps) if steps else np.zeros(0, dtype=np.int64)
+    n_total = N * copies
+    order = _block_shuffled_order(n_total, shuffle_seed) if shuffle_seed is not None else np.arange(n_total, dtype=np.int64)
+    inv = np.empty(n_total, dtype=np.int64)
+    inv[order] = np.arange(n_total)
+    node_len = np.tile(g.node_len, copies)
+    max_id = int(g.node_ids.max()) if N else 0
+    ids = (g.node_ids.astype(np.int64)[None, :] + (np.arange(copies, dtype=np.int64) * max_id)[:, None]).reshape(-1)
+    sn = np.where(steps0 == NO_NODE, NO_NODE, inv[np.minimum(steps0, max(n_total - 1, 0))])
+    return FlatGraph(
+        node_len=node_len[order].astype(np.uint32),
+        step_node=sn.astype(np.uint32),
+        step_is_rev=(np.concatenate(revs) if revs else np.zeros(0)).astype(np.uint8),
+        path_first_step=np.concatenate([[0], np.cumsum(counts * copies)]).astype(np.uint64),
+        node_ids=ids[order].astype(np.uint64),
+        path_names=list(g.path_names),
+    )
+
+
 def synth_chain(n_nodes: int, seed: int, shuffle: bool = True) -> FlatGraph:
     """`chain(N,seed)`: one path 1+,..,N+ over a linear chain; S lines block-shuffled."""
     return synth_windows(n_nodes, 1, n_nodes, seed, shuffle)

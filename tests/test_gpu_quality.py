@@ -14,7 +14,7 @@ Instruments (gfasort_amd/quality.py):
 import numpy as np
 import pytest
 
-from util import O, G, P, oracle_graph, oracle_params
+from util import O, G, P, load, oracle_graph, oracle_params
 from gfasort_amd import hip, quality as Q
 
 pytestmark = pytest.mark.gpu
@@ -71,21 +71,25 @@ def test_default_flags_on_a_525k_node_bubble_graph_against_the_cpu_oracle_and_re
     assert stm.n_streams == 262_464 and stm.bundle == 64 and stm.launches - before == p.iter_max + 1 and stm.term_updates == st.term_updates
     _compare(g, og, x_b1, x_many, "more streams than resident workgroups vs GPU reference streams")
     # Work pools: the precision at path distance 1 does not depend on the stream count.  With round 1's launch (a fixed quota per
-    # wave, free-running waves that drift apart in the schedule) 209 920 streams was a bad count on this graph: relative error
-    # 0.217-0.228 at distance 1 against reference streams' 0.194; with the pools 0.19 at every count (profiles/r02/pacing.log).
+    # wave, free-running waves that drift apart in the schedule) 209 920 streams was a bad count on this graph.  Measured over
+    # ALL 9.75e6 adjacent step pairs (Q.short_range_error): 0.1928-0.1937 with pools at either count over three seeds, 0.204
+    # for reference streams (profiles/r03/d1_outliers.log).  (Round 2 measured a 50 000-pair sample of it and saw 0.189-0.218:
+    # the squared relative error at distance 1 is heavy-tailed — the worst ten pairs of 9.75e6 carry 0.6-2 % of the mean
+    # square — and a sample swings by +-7 % with whether it hits one of them; the same seed gave the same "outlier" twice
+    # because the same pairs were sampled: profiles/r03/pool_seed_study.log.)
     ctx = hip.Context(g)
-    prof = {}
+    d1 = {}
     for name, fl in (("pools", 0), ("free-running", hip.F_DBG_FREE_RUNNING)):
         ctx.setup_1d(p, hip.make_config(n_streams=209_920, flags=fl))
         ctx.init_positions()
         ctx.run()
         assert ctx.stats().term_updates == st.term_updates
-        prof[name] = _profile(g, ctx.download())
+        d1[name] = Q.short_range_error(g, ctx.download(), 0, (1,))["rms"]
     ctx.close()
-    d1_ref = _profile(g, x_b1)[0]
-    # pools: 0.189-0.205 over many runs (0.191 typical); free-running: 0.213-0.228.  Only the first is asserted — with a margin
-    # for the run-to-run spread of a concurrent kernel; the second is in the message for whoever reads a failure.
-    assert prof["pools"][0] <= 1.10 * d1_ref, (prof["pools"][0], d1_ref, "free-running:", prof["free-running"][0])
+    d1_ref, d1_def = Q.short_range_error(g, x_b1, 0, (1,))["rms"], Q.short_range_error(g, x_def, 0, (1,))["rms"]
+    assert d1["pools"] <= 1.02 * d1_ref and d1_def <= 1.02 * d1_ref, (d1, d1_def, d1_ref)
+    assert abs(d1["pools"] - d1_def) <= 0.015 * d1_def, (d1, d1_def)            # the stream count does not matter
+    assert d1["free-running"] >= 1.08 * d1["pools"], d1                          # ... and the pools are what makes it so
     # the CPU oracle, executed as the reference executes: worker threads + checker thread (flat arrays, all host cores)
     import os
     op = oracle_params(p)
@@ -116,6 +120,136 @@ def test_default_flags_on_a_2m_node_bubble_graph_against_reference_streams():
     with pytest.raises(AssertionError):
         _compare(g, og, x_b1, x_r1, "round-1 sampler")
     assert res["tau"] > 0.9999
+
+
+# ---- the DEFAULT layout kernel (sgdnd_team_kernel<D,64>: one set of end flips per run where sgd.rs:1062,1071 draw them per
+# ---- term, two partners per leader, twin trips) on large graphs, against the CPU oracle and GPU reference streams -----------
+def _layout_profile(g, c, dims):
+    _, rms, cnt = Q.stress_by_scale(g, c, dims, 1_000_000)
+    return rms
+
+
+def _end_to_end(g, c, dims):
+    """|distance between a node's two ends - its length| (what a layout of a sequence graph must get right first)"""
+    cc = np.asarray(c).reshape(-1, 2, dims)
+    d = np.sqrt(((cc[:, 0, :] - cc[:, 1, :]) ** 2).sum(axis=1))
+    err = np.abs(d - g.node_len)
+    return float(np.median(err)), float(np.mean(err))
+
+
+def _compare_layout(g, og, dims, c_ref, c_new, what, tol_stress=0.10, tol_octave=0.12):
+    s_ref, s_new = O.layout_stress(og, dims, c_ref, 2_000_000), O.layout_stress(og, dims, c_new, 2_000_000)
+    assert s_new <= (1.0 + tol_stress) * s_ref, (what, "sampled layout stress", s_ref, s_new)
+    pr, pn = _layout_profile(g, c_ref, dims), _layout_profile(g, c_new, dims)
+    worst = float(np.max(pn / pr))
+    assert worst <= 1.0 + tol_octave, (what, "relative error by octave of path distance", np.round(pn / pr, 3).tolist())
+    (m_ref, a_ref), (m_new, a_new) = _end_to_end(g, c_ref, dims), _end_to_end(g, c_new, dims)
+    assert m_new <= 1.10 * m_ref + 0.02 and a_new <= 1.10 * a_ref + 0.02, (what, "node end-to-end distance vs length", (m_ref, a_ref), (m_new, a_new))
+    return dict(stress=(s_ref, s_new), worst_octave=worst, end_to_end=((m_ref, a_ref), (m_new, a_new)))
+
+
+def test_default_layout_flags_on_a_525k_node_bubble_graph_against_the_cpu_oracle_and_reference_streams():
+    """`-p L --dimensions 2` with ALL-DEFAULT flags on the 525k-node bubble graph: the team kernel the library picks
+    (B = 64, runs of 16 trips, two partners) against (i) the CPU oracle run as the reference runs its layout — worker
+    threads + checker thread, sgd.rs:925-1164 — and (ii) reference streams on the GPU, at equal update counts from the same
+    start: sampled layout stress (2M pairs), relative error per octave of path distance, node end-to-end distance."""
+    import os
+    from gfasort_amd import sgd as S
+    g = G.synth_bubbles(400_000, 24, 6)
+    p = P.LayoutSGDParams.from_graph(g, 2, 1)                    # the CLI's defaults: 31 iterations of 10 x steps
+    og = oracle_graph(g)
+    c0 = S.default_layout_init(g, 2, p.seed)
+    rc, c_def, st = hip.path_linear_sgd_layout_raw(g, p, c0)
+    assert rc == 0 and st.bundle == 64 and st.term_updates == (p.iter_max + 1) * p.min_term_updates
+    rc, c_b1, st1 = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(flags=hip.F_BUNDLE(1)))
+    assert rc == 0 and st1.bundle == 1 and st1.term_updates == st.term_updates
+    res = _compare_layout(g, og, 2, c_b1, c_def, "default layout flags vs GPU reference streams")
+    op = oracle_params(p)
+    op.nthreads = max(2, min(16, len(os.sched_getaffinity(0))))
+    c_cpu = c0.copy()
+    rc, cst = O.sgd_nd_threads(og, op, c_cpu, flat=1)
+    assert rc == 0 and cst.iterations >= p.iter_max
+    assert 0.99 <= cst.term_updates / st.term_updates < 1.15, cst.term_updates / st.term_updates
+    _compare_layout(g, og, 2, c_cpu, c_def, "default layout flags vs the CPU oracle (threads)")
+    _compare_layout(g, og, 2, c_cpu, c_b1, "GPU layout reference streams vs the CPU oracle (threads)")
+    s0 = O.layout_stress(og, 2, c0, 200_000)
+    assert res["stress"][1] < 0.1 * s0
+
+
+def test_default_layout_flags_in_3_dimensions_against_reference_streams():
+    from gfasort_amd import sgd as S
+    g = G.synth_bubbles(150_000, 16, 9)                          # 196 875 nodes, 16 haplotypes
+    p = P.LayoutSGDParams.from_graph(g, 3, 1)
+    og = oracle_graph(g)
+    c0 = S.default_layout_init(g, 3, p.seed)
+    rc, c_def, st = hip.path_linear_sgd_layout_raw(g, p, c0)
+    assert rc == 0 and st.bundle == 64 and st.term_updates == (p.iter_max + 1) * p.min_term_updates
+    rc, c_b1, st1 = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(flags=hip.F_BUNDLE(1)))
+    assert rc == 0 and st1.bundle == 1
+    _compare_layout(g, og, 3, c_b1, c_def, "default 3-D layout flags vs GPU reference streams")
+
+
+# ---- default flags on REAL pangenome structure at scale: the reference's DRB1-3123 fixture tiled in series -----------------
+@pytest.mark.parametrize("shuffle_seed", [None, 17])
+def test_default_flags_on_drb1_tiled_in_series(shuffle_seed):
+    """tests/data/DRB1-3123.gfa (the fixture of integration_tests.rs:147-172: 4 955 nodes, nested bubbles, kilobase insertions,
+    one haplotype on the reverse strand) 120 times in series: 594 600 nodes, 12 haplotype paths of up to 372 000 steps,
+    371 520 reverse steps — from the fixture's own node order and from block-shuffled S lines (unsorted input is what gfasort
+    exists for).  The auto policy must pick the team kernel (B = 64, long runs).
+
+    What was found (profiles/r03/tiled_probe*.log).  On this graph the reference's default schedule (--iter-max 100) does NOT
+    converge, for any sampler: reference streams and the CPU oracle end at a relative error of 26-29 (2 800 %) at path
+    distance 1 and a rank RMSE of 195 bp; a schedule of 300 iterations ends at 12 and 125 bp, one of 1000 at 7.4 and 104 bp.
+    (a) At the schedule lengths where the layout converges the default sampler is at parity or BETTER in every octave and in
+        RMSE — asserted here at --iter-max 300 with the thresholds of the bubble-graph tests, against reference streams and
+        against the CPU oracle run as the reference runs (threads + checker).
+    (b) At the unconverged point of --iter-max 100 it is BEHIND: +60-70 % at distance 1, +10-16 % from 32 steps up, RMSE +22 %,
+        sampled stress +4-12 % — whatever the run length (K = 1...128), the partners, the stream count (16k...262k) or the launch:
+        correlated terms are fewer independent samples per update, and an annealing schedule that is too short for the graph
+        shows it.  Asserted as measured (bounds with ~15 % of head room), so that a regression is caught and the gap stays on
+        record; `GFS_F_BUNDLE(1)` / `gfasort_hip --reference-sampler` runs the reference's own sampler (8x slower)."""
+    import os
+    g = G.tile_series(load("DRB1-3123.gfa"), 120, shuffle_seed=shuffle_seed)
+    assert g.n_nodes == 594_600 and int(g.step_is_rev.sum()) == 371_520
+    og = oracle_graph(g)
+    ctx = hip.Context(g)
+    res = {}
+    for iter_max in (300, 100):
+        p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+        p.iter_max = iter_max
+        x_def, st = _run_default(ctx, p)
+        assert st.bundle == 64 and st.run_trips == 64 and st.term_updates == (p.iter_max + 1) * p.min_term_updates
+        l0 = st.launches
+        x_b1, st1 = _run_default(ctx, p, hip.F_BUNDLE(1))
+        assert st1.bundle == 1 and st1.launches - l0 == 1 and st1.term_updates == st.term_updates     # (launches: over the context's life)
+        res[iter_max] = (x_def, x_b1)
+    ctx.close()
+    # (a) converged schedule: parity
+    x_def, x_b1 = res[300]
+    _compare(g, og, x_b1, x_def, "DRB1 x120 --iter-max 300, default flags vs GPU reference streams")
+    if shuffle_seed is None:
+        p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+        p.iter_max = 300
+        op = oracle_params(p)
+        op.nthreads = max(2, min(16, len(os.sched_getaffinity(0))))
+        x_cpu = O.init_positions(og)
+        rc, cst = O.sgd_1d_threads(og, op, x_cpu, flat=1)
+        assert rc == 0 and cst.iterations >= p.iter_max
+        assert 0.99 <= cst.term_updates / (301 * p.min_term_updates) < 1.25
+        _compare(g, og, x_cpu, x_def, "DRB1 x120 --iter-max 300, default flags vs the CPU oracle (threads)")
+    # (b) the reference's default schedule: behind, by a bounded amount
+    x_def, x_b1 = res[100]
+    s_ref, s_def = O.stress_1d(og, x_b1, 2_000_000), O.stress_1d(og, x_def, 2_000_000)
+    assert s_def <= 1.15 * s_ref, (s_ref, s_def)               # measured +4...12 %
+    pr, pn = _profile(g, x_b1), _profile(g, x_def)
+    ratio = pn / pr
+    assert ratio[0] <= 2.0 and np.max(ratio[1:]) <= 1.30, np.round(ratio, 3).tolist()
+    q_ref = Q.layout_quality(g, hip.sort_order(x_b1).astype(np.int64))
+    q_def = Q.layout_quality(g, hip.sort_order(x_def).astype(np.int64))
+    assert q_def["rmse"] <= 1.40 * q_ref["rmse"], (q_ref, q_def)
+    r_ref = Q.ranks_of(hip.sort_order(x_b1).astype(np.int64))
+    r_def = Q.oriented(r_ref, Q.ranks_of(hip.sort_order(x_def).astype(np.int64)))
+    assert Q.kendall_tau(r_ref, r_def) >= 0.99
 
 
 def test_more_than_4_million_paths():
