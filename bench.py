@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_1D = 64          # 2 step records x16 B + 2 position reads x8 B + 2 writes x8 B
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+ATOMIC_UNIT_PEAK = 23.6e9   # 64-B f64 atomic requests/s the memory side executes, whole chip, measured (profiles/r01/ubench_scattered_ops.log)
 
 
 def build_workload(world=1):
@@ -175,8 +176,11 @@ def reference_streams_leg(g, p, device_index, args, steps=60):
 
 
 def layout_leg(g, device_index, args, dims=2):
-    """BASELINE configs[3]: the same graph, -p L --dimensions 2 (31 iterations of 1e8 updates), resident in HBM."""
-    from gfasort_amd import hip, params as P, sgd as S
+    """BASELINE configs[3]: the same graph, -p L --dimensions 2 (31 iterations of 1e8 updates), resident in HBM.  Plus what
+    the `bubbles` leg does for the sort: the default layout kernel against reference streams (GFS_F_BUNDLE(1)) on the 525k-node
+    bubble graph at equal update counts from the same start — layout stress (the reference's formula, sgd.rs:1196, 2M pairs)
+    and the worst ratio of the relative error over the octaves of path distance — and the wall clock of the CLI's `-p L`."""
+    from gfasort_amd import hip, params as P, sgd as S, graph as G, quality as Q
     p = P.LayoutSGDParams.from_graph(g, dims, 1)
     ctx = hip.Context(g, device=device_index)
     ctx.setup_nd(p, hip.make_config(n_streams=args.streams, flags=args.flags | hip.F_BUNDLE(args.bundle), block_size=args.block))
@@ -194,35 +198,64 @@ def layout_leg(g, device_index, args, dims=2):
     launches = max(int(s1.launches - s0.launches), 1)
     kms = (s1.kernel_ms - s0.kernel_ms) / launches
     algo = 40 + 32 * dims                                  # 2 records x 16 B + 2 ends x D x (8 read + 8 write) + ...
-    return {"value": upd / dt, "unit": "term-updates/s", "dimensions": dims, "steps": launches,
-            "sampling_bundle": int(s1.bundle), "avg_launch_ms": kms, "algorithmic_bytes_per_update": algo,
-            "roofline_frac": (upd / launches) * algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out = {"value": upd / dt, "unit": "term-updates/s", "dimensions": dims, "steps": launches,
+           "sampling_bundle": int(s1.bundle), "run_trips": int(s1.run_trips), "avg_launch_ms": kms, "algorithmic_bytes_per_update": algo,
+           "roofline_frac": (upd / launches) * algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # quality of the default layout kernel against reference streams, 525k-node bubble graph
+    gb = G.synth_bubbles(400_000, 24, 6)
+    pb = P.LayoutSGDParams.from_graph(gb, dims, 1)
+    c0 = S.default_layout_init(gb, dims, pb.seed)
+    res = {}
+    for name, flags in (("default_flags", args.flags | hip.F_BUNDLE(args.bundle)), ("reference_streams", hip.F_BUNDLE(1))):
+        rc, c, st = hip.path_linear_sgd_layout_raw(gb, pb, c0, cfg=hip.make_config(n_streams=args.streams, flags=flags, block_size=args.block))
+        _, rms, _ = Q.stress_by_scale(gb, c, dims, 1_000_000)
+        res[name] = {"value": st.term_updates / (st.kernel_ms * 1e-3), "unit": "term-updates/s", "sampling_bundle": int(st.bundle),
+                     "term_updates": int(st.term_updates), "layout_stress_2M_pairs": Q.sampled_stress(gb, c, dims, 2_000_000), "_rms": rms}
+    ratio = res["default_flags"].pop("_rms") / res["reference_streams"].pop("_rms")
+    out["bubbles_525k"] = dict(res, workload="synth_bubbles(400000,24,6), -p L --dimensions %d --layout-iter 30" % dims,
+                               stress_ratio_default_over_reference_streams=res["default_flags"]["layout_stress_2M_pairs"] /
+                               res["reference_streams"]["layout_stress_2M_pairs"],
+                               worst_error_ratio_over_octaves_of_path_distance=float(ratio.max()))
+    return out
 
 
-def wall_clock_leg(g):
-    """The other half of BASELINE's metric: wall-clock of the whole `-p Y --iter-max 200` run,
-    GFA text in -> sorted GFA text out, through the C++ CLI (gfasort_amd/bin/gfasort_hip)."""
-    import subprocess
-    import tempfile
-    from gfasort_amd import build as B
-    if not os.path.exists(B.CLI):
-        return None
-    d = tempfile.mkdtemp(prefix="gfs_bench_")
-    src, dst = os.path.join(d, "c3.gfa"), os.path.join(d, "c3.sorted.gfa")
-    with open(src, "w") as fh:
+def _write_gfa(g, path):
+    with open(path, "w") as fh:
         fh.write("H\tVN:Z:1.0\n")
         fh.write("".join(f"S\t{i}\t{'A' * l}\n" for i, l in zip(g.node_ids.tolist(), g.node_len.tolist())))
         fh.write("".join(f"L\t{i}\t+\t{i + 1}\t+\t0M\n" for i in range(1, g.n_nodes)))
         first = g.path_first_step.astype(np.int64)
         for pth, name in enumerate(g.path_names):
             fh.write(f"P\t{name}\t" + ",".join(f"{i}+" for i in g.step_node_id[first[pth]:first[pth + 1]].tolist()) + "\t*\n")
+
+
+def wall_clock_leg(g, pipeline="Y"):
+    """The other half of BASELINE's metric: wall-clock of the whole run, GFA text in -> GFA text (and layout TSV) out, through
+    the C++ CLI (gfasort_amd/bin/gfasort_hip): `-p Y --iter-max 200` (configs[2]) or `-p L --dimensions 2` (configs[3],
+    src/bin/gfasort.rs:265-292)."""
+    import subprocess
+    import tempfile
+    from gfasort_amd import build as B
+    if not os.path.exists(B.CLI):
+        return None
+    d = tempfile.mkdtemp(prefix="gfs_bench_")
+    src, dst, tsv = os.path.join(d, "c3.gfa"), os.path.join(d, "c3.out.gfa"), os.path.join(d, "c3.layout.tsv")
+    _write_gfa(g, src)
+    cmd = [B.CLI, "-i", src, "-o", dst, "-p", pipeline, "-v", "1"] + \
+          (["--iter-max", "200"] if pipeline == "Y" else ["--dimensions", "2", "--layout-out", tsv])
     t0 = time.perf_counter()
-    r = subprocess.run([B.CLI, "-i", src, "-o", dst, "-p", "Y", "--iter-max", "200", "-v", "1"], capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
     phases = [ln for ln in r.stderr.split("\n") if ln.startswith("[gfasort] done")]
+    engine = [ln for ln in r.stderr.split("\n") if ln.startswith("[gfasort_hip]")]
     out = {"seconds": dt, "returncode": r.returncode, "input_mb": os.path.getsize(src) / 1e6,
-           "command": "gfasort_hip -i c3.gfa -o c3.sorted.gfa -p Y --iter-max 200", "phases": phases[0] if phases else ""}
-    for f in (src, dst):
+           "command": "gfasort_hip -i c3.gfa -o c3.out.gfa " + " ".join(cmd[5:]).replace(tsv, "c3.layout.tsv"),
+           "phases": phases[0] if phases else "", "engine": engine[0] if engine else ""}
+    if pipeline == "L":
+        out["layout_stress_10k_pairs"] = next((float(ln.split("layout stress:")[1].split()[0]) for ln in r.stderr.split("\n")
+                                               if "layout stress:" in ln), None)
+        out["layout_tsv_mb"] = os.path.getsize(tsv) / 1e6 if os.path.exists(tsv) else None
+    for f in (src, dst, tsv):
         try:
             os.remove(f)
         except OSError:
@@ -265,8 +298,10 @@ def main():
     ap.add_argument("--steps", type=int, default=201)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-priming", action="store_true",
-                    help="do not run the untimed launch of the timed shape after the warm-up steps")
+    ap.add_argument("--priming", action="store_true",
+                    help="profiling runs only: after the warm-up steps, one untimed launch of the timed shape (both dispatches of the fused "
+                         "kernel are then of one shape and its rocprofv3 --stats average is the timed launch's duration); disclosed in "
+                         "config.untimed_priming_launch.  Default: the warm-up is exactly the --warmup steps")
     ap.add_argument("--leg", default="", help="internal: run ONE extra leg in this process and print its JSON")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="only the timed region: skip the quality / bubbles / reference_streams / layout_2d legs (PMC passes)")
@@ -278,6 +313,7 @@ def main():
                          "iteration, as BASELINE's north_star has it")
     ap.add_argument("--whole-vector", action="store_true", help="N>1: exchange the whole position vector, not only the shared slots")
     ap.add_argument("--payload-f64", action="store_true", help="N>1: f64 exchange buffer instead of f32")
+    ap.add_argument("--no-layout-leg", action="store_true", help="N>1: skip the sharded `-p L` leg")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-fuse", action="store_true",
                     help="one kernel launch per iteration instead of one fused persistent launch per merge window")
@@ -349,12 +385,11 @@ def main():
     for s in range(args.warmup):
         runner.run_iteration(s % n_sched)
     sync_all()
-    # ... and ONE untimed launch of exactly the timed shape: the first dispatch of a kernel function costs ~0.12 ms
-    # between the start event and the kernel's first wave (profiles/r02/launch_gap.log: 2.78-2.80 ms by HIP events for the
-    # first fused launch of a process, 2.65-2.68 ms for every later one; the kernel trace shows 2.65-2.67 ms for all of
-    # them).  With both dispatches of the fused kernel of the same shape its rocprofv3 --stats average stays the figure
-    # reported below.  Disclosed as config.untimed_priming_launch.
-    if not args.no_priming:
+    # (--priming, profiling runs only: ONE untimed launch of exactly the timed shape.  The first dispatch of a kernel function
+    # spends ~0.12 ms between the start event and the kernel's first wave — profiles/r02/launch_gap.log — which the HIP events
+    # of a timed first dispatch include and the kernel trace does not: 5 % of the driver's 20-step launch, 0.6 % of the default
+    # 201-step one.  The default run does not prime: its timed number is what --warmup W --steps K says.)
+    if args.priming:
         runner.run_range([s % n_sched for s in range(args.steps)])
         sync_all()
     runner.reset_streams()
@@ -385,7 +420,16 @@ def main():
         runner.profile = False
         sync_all()
         info = runner.info
-        multi = {"merge_every": args.merge_every, "windows_profiled": tm["windows"],
+        # what actually carried the collective: the library torch.distributed reports, the communicator's size, the device every
+        # rank bound (gathered, so that the record itself shows N distinct GPUs — or the rehearsal's shared one)
+        devs = [None] * world
+        dist.all_gather_object(devs, {"rank": rank, "local_rank": local_rank, "cuda_device": int(torch.cuda.current_device()),
+                                      "device_name": torch.cuda.get_device_name(torch.cuda.current_device()),
+                                      "uuid": str(getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "uuid", ""))})
+        multi = {"collective": {"torch_distributed_backend": str(dist.get_backend()), "world_size": int(dist.get_world_size()),
+                                "is_rccl": str(dist.get_backend()) == "nccl" and bool(getattr(torch.version, "hip", None)),
+                                "shared_device_rehearsal": bool(share), "ranks": devs},
+                 "merge_every": args.merge_every, "windows_profiled": tm["windows"],
                  "compute_ms_per_window": tm["compute_ms"] / max(tm["windows"], 1),
                  "exchange_ms_per_window": tm["exchange_ms"] / max(tm["windows"], 1),
                  "exchange_bytes_per_window": tm["exchange_bytes_per_window"],
@@ -419,6 +463,32 @@ def main():
                                       "exchange_ms_per_window": tm4["exchange_ms"] / max(tm4["windows"], 1),
                                       "windows_profiled": tm4["windows"]}
             runner.windows = _Windows(p.iter_max, args.merge_every, True)
+        # second leg: the layout step (`-p L --dimensions 2`) of the same graph, sharded the same way: coordinates of both ends
+        # of the shared slots are exchanged per iteration (2 planes x 2 dims); a few iterations are enough for a rate
+        if not args.no_layout_leg:
+            from gfasort_amd import params as PP, sgd as SS
+            pl = PP.LayoutSGDParams.from_graph(g, 2, 1)
+            lay = RankDriver(g, pl, rank, world, dims=2, device_index=local_rank, streams_per_rank=args.streams,
+                             flags=args.flags | hip.F_BUNDLE(args.bundle), block_size=args.block, dist=dist,
+                             merge_every=args.merge_every, whole_vector=args.whole_vector, payload_f64=args.payload_f64)
+            lay.set_positions(SS.default_layout_init(g, 2, pl.seed).ravel())
+            lay.run_iteration(0)
+            sync_all()
+            ul0 = lay.stats().term_updates
+            n_l = min(args.steps, 8)
+            tl = time.perf_counter()
+            lay.run_range(list(range(1, 1 + n_l)))
+            sync_all()
+            dtl = torch.tensor([time.perf_counter() - tl], dtype=torch.float64, device="cuda")
+            dist.all_reduce(dtl, op=dist.ReduceOp.MAX)
+            ul = torch.tensor([float(lay.stats().term_updates - ul0)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ul, op=dist.ReduceOp.SUM)
+            multi["layout_2d"] = {"value": float(ul.item()) / float(dtl.item()), "unit": "term-updates/s", "steps": n_l,
+                                  "term_updates_per_step": int(pl.min_term_updates), "dimensions": 2,
+                                  "exchange_bytes_per_window": int(lay.info.exchange_count) * (8 if args.payload_f64 else 4),
+                                  "roofline_frac_per_gpu": float(ul.item()) / float(dtl.item()) * 104 / 1e9 / HBM_PEAK_GBS / world}
+            lay.close()
+            sync_all()
         # the same workload on ONE GPU (rank 0's), so that the scaling of THIS workload can be read off this line
         if rank == 0:
             ctx1 = hip.Context(g, device=local_rank)
@@ -445,13 +515,14 @@ def main():
         achieved = upd_per_launch * ALGO_BYTES_1D / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         # HBM traffic is a PMC measurement (separate rocprofv3 --pmc passes, MI355X_MICROARCH.md) and cannot be taken
         # inside this run: the figure of the committed passes over this same command is scaled to this launch and LABELLED
-        traffic, traffic_source = None, None
+        traffic, traffic_source, per_update, atomic_req = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if world == 1 and os.path.exists(tpath):
             try:
                 with open(tpath) as fh:
                     tj = json.load(fh)
                 per_update = tj.get("hbm_bytes_per_update")
+                atomic_req = tj.get("atomic_requests_per_update")
                 traffic = per_update * upd_per_launch if per_update else None
                 traffic_source = ("NOT measured in this run: " + str(tj.get("source", "profiles/traffic_latest.json")) +
                                   f" ({per_update:.1f} B per update) scaled to this launch's updates")
@@ -471,11 +542,12 @@ def main():
                                    "updates from a shared pool — a departure from the reference's independent terms, see DESIGN.md 3 "
                                    "and the quality / bubbles legs") if int(st1.bundle) == 64 and not (args.flags & 0x30) else
                                   "as selected by --flags",
-                       "untimed_priming_launch": None if args.no_priming else
-                       f"after the {args.warmup} warm-up steps, the {args.steps} steps of the timed region once, untimed, from the "
+                       "untimed_priming_launch": None if not args.priming else
+                       f"--priming: after the {args.warmup} warm-up steps, the {args.steps} steps of the timed region once, untimed, from the "
                        "same start (first-dispatch latency of the kernel function, ~0.12 ms, is not kernel time)",
-                       "parallelism": f"paths sharded x{world} (consecutive blocks), one RCCL all-reduce of [delta,touched] "
-                                      f"over the slots two or more ranks can move, every {args.merge_every} iteration(s)"
+                       "parallelism": f"paths sharded x{world} (consecutive blocks), one all-reduce of [delta,touched] "
+                                      f"over the slots two or more ranks can move, every {args.merge_every} iteration(s), through "
+                                      f"torch.distributed backend '{dist.get_backend()}' (see multi_gpu.collective)"
                        if world > 1 else "single GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -484,7 +556,16 @@ def main():
                          "launches": launches, "iterations_per_launch": args.steps / launches,
                          "term_updates_per_launch": upd_per_launch,
                          "avg_launch_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_update": ALGO_BYTES_1D},
+                         "algorithmic_bytes_per_update": ALGO_BYTES_1D,
+                         # the same launch against two other yardsticks, both from the committed PMC passes (profiles/traffic_latest.json),
+                         # NOT measured in this run: the HBM bytes the counters saw per update, and the requests to the memory-side
+                         # atomic units — what actually binds this kernel — against the rate a micro-benchmark measured for them
+                         "frac_counter_bytes": (per_update * upd_per_launch / avg_kernel_s / 1e9 / HBM_PEAK_GBS)
+                         if per_update and avg_kernel_s > 0 else None,
+                         "counter_bytes_per_update": per_update,
+                         "atomic_unit_frac": (atomic_req * upd_per_launch / avg_kernel_s / ATOMIC_UNIT_PEAK)
+                         if atomic_req and avg_kernel_s > 0 else None,
+                         "atomic_requests_per_update": atomic_req, "atomic_unit_peak_requests_per_s": ATOMIC_UNIT_PEAK},
             "total_term_updates": total_updates,
         }
         if multi is not None:
@@ -494,7 +575,8 @@ def main():
             for name in legs:
                 out[name] = run_leg(name, args)
         if world == 1 and not args.no_cpu_baseline:
-            out["wall_clock_pY"] = wall_clock_leg(g)
+            out["wall_clock_pY"] = wall_clock_leg(g, "Y")
+            out["wall_clock_pL"] = wall_clock_leg(g, "L")
             out["cpu_baseline"] = cpu_baseline(g, p)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -437,22 +437,25 @@ static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
 static int choose_bundle(gfs_ctx *c, int dims) {
     const uint64_t T = c->n_streams;
     uint32_t b = (c->cfg.flags >> 16) & 0xFFu;
+    const bool b_auto = b == 0;
     if (b > 1 && (T % 64 != 0 || (b != 4 && b != 8 && b != 16 && b != 32 && b != 64)))
         return fail(GFS_E_ARG, "bundled sampling needs n_streams % 64 == 0 and a bundle of 4, 8, 16, 32 or 64");
     if (b > 1 && dims != 0 && (dims > 3 || b == 4))
         return fail(GFS_E_UNSUPPORTED, "bundled layout kernels exist for 1..3 dimensions and bundles of 8..64");
     if (b == 0) {
-        // auto: the widest bundle that still leaves >= 4096 independent leader draws per iteration and has
-        // >= 95 % of the steps in paths of at least 4*B steps, on graphs of >= 16384 nodes.  Measured at equal
-        // update counts (profiles/r01/bundle_quality_mid.log, bundle_quality_team.log): bubble graphs of 26k /
-        // 79k / 197k / 525k nodes end at stress 0.0068 / 0.0040 / 0.0030 / 0.0022 with B = 64 against 0.0069 /
-        // 0.0038 / 0.0027 / 0.0020 with reference streams, 2.4-4.4x faster; DRB1 (5k nodes) converges visibly
-        // slower with bundles (0.34 vs 0.32 after 100 iterations), so small graphs run reference streams.
+        // auto (measured: profiles/r03/policy_sweep.log — bubble graphs of 16k...300k nodes, three seeds per cell, the relative
+        // error per octave of path distance against reference streams): on graphs of >= 16 384 nodes the widest bundle for
+        // which >= 95 % of the steps lie in paths of at least 4*B steps.  B = 64 with long runs is within 2-7 % of reference
+        // streams in every octave from 16k nodes up and 2-10 times faster; narrower bundles and runs of one trip are both slower
+        // and worse (+16...42 % at 64-127 steps from 131k nodes up: a run's two blocks move rigidly and leave a step at their edges,
+        // short runs have more edges).  Round 2's extra condition — ">= 4096 independent leader draws per iteration" — is gone:
+        // graphs with 37-99 leader draws per iteration are in that table and are as good as those with thousands; the run
+        // length, not the number of leaders, is what the quality follows (bounded below by a floor of 64 leaders, see K).
+        // Smaller graphs run reference streams: DRB1 (5k nodes) converged visibly slower with bundles (round 1).
         b = 1;
         if (T % 64 == 0 && dims <= 3 && c->n_nodes >= 16384) {
             for (uint32_t cand : {64u, 32u, 16u, 8u, 4u}) {
                 if (cand == 4u && dims != 0) continue;
-                if (c->quota_total / cand < 4096) continue;
                 uint64_t long_steps = 0;
                 for (uint32_t cnt : c->path_counts) if (cnt >= 4 * cand) long_steps += cnt;
                 if ((double)long_steps >= 0.95 * (double)c->n_steps) { b = cand; break; }
@@ -468,11 +471,17 @@ static int choose_bundle(gfs_ctx *c, int dims) {
     if (k > 64 || (k & (k - 1))) return fail(GFS_E_ARG, "GFS_F_CHAIN: the run length in trips must be a power of two <= 64");
     // (layout kernels: 16 — on C4 runs of 64 trips cost 13 % of the rate, 30.8 against 34.2-35.5 G updates/s, and the error
     // profile of the 2-D layout is already below reference streams' at 16: profiles/r02/quality_probe_layout_k.log)
+    const bool k_auto = k == 0;
     if (k == 0) k = dims ? 16 : 64;
-    c->chain = b == 64 ? k : 1;                       // (nD: team kernels exist for D <= 3; checked above)
     // Two partners per leader (sgd_device.h Leader): the team kernels at B = 64 (1D; layouts of 2 and 3 dimensions), unless
     // GFS_F_ONE_PARTNER
     c->partners = (b == 64 && (dims == 0 || dims == 2 || dims == 3) && !(c->cfg.flags & GFS_F_ONE_PARTNER)) ? 2u : 1u;
+    // ... auto: and short enough that an iteration still draws >= 64 leaders (a leader stands for up to 64 * K * partners
+    // terms): at 16k nodes runs of 32 trips left 37 leaders per iteration and +6 % at path distance 1, runs of 16 (74 leaders)
+    // +1 %; from 32k nodes up 37 leaders were within 3 % (same table).  Binds only below ~500k steps.
+    // (only where the library picked the bundle as well: an explicit GFS_F_BUNDLE(64) keeps 64 / 16)
+    if (k_auto && b_auto && b == 64) while (k > 1 && c->quota_total / (64ull * k * c->partners) < 64) k >>= 1;
+    c->chain = b == 64 ? k : 1;                       // (nD: team kernels exist for D <= 3; checked above)
     return GFS_OK;
 }
 

@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -66,14 +67,15 @@ __global__ void exchange_prepare_kernel(const double *x, const double *x_prev, T
         buf[total + e] = d != 0.0 ? (T)1 : (T)0;
     }
 }
-// x_prev += sum_delta / divisor; x = x_prev.  rule 0: divisor = max(1, ranks that moved the node); 1: 1; 2: world
+// x_prev += sum_delta / divisor; x = x_prev.  rule 0: divisor = max(1, ranks that moved the node); 1: 1; 2: world;
+// 3: max(1, ranks that moved the node x cscale), cscale in (0, 1] falling with the window's learning rate (gfs_rank_window_end)
 template <typename T>
 __global__ void exchange_apply_kernel(double *x, double *x_prev, const T *buf, const ESeg *segs, uint32_t n_segs, uint64_t total,
-                                      double divide_all_by) {
+                                      double divide_all_by, double cscale) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const ESeg s = segs[find_seg(segs, n_segs, e)];
-        const double c = (double)buf[total + e];
+        const double c = (double)buf[total + e] * cscale;
         const double div = divide_all_by > 0.0 ? divide_all_by : (c > 1.0 ? c : 1.0);
         const double v = x_prev[e] + (double)buf[e] / div;
         x_prev[e] = v;
@@ -314,6 +316,9 @@ struct gfs_rank {
     double *d_full = nullptr;            // finish: full-length scratch when the caller binds none
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double merge_ms = 0.0; uint64_t windows = 0; bool ev_pending = false;
+    std::vector<double> etas;            // the schedule (merge rule 3)
+    double eta_sum = 1.0;                // learning rate below which a window's moves are small enough to be summed (merge rule 3)
+    uint64_t win_last_k = 0, win_len = 1;
 };
 
 static size_t payload_size(const gfs_rank *r) { return r->cfg.payload ? sizeof(double) : sizeof(float); }
@@ -339,7 +344,7 @@ int gfs_rank_create(const gfs_graph_view *g, const gfs_sgd_params *p, uint64_t d
     if (cfg->world == 0 || cfg->rank >= cfg->world) return gfs_set_error(GFS_E_ARG, "rank must be < world");
     if (cfg->world > GFS_MAX_WORLD) return gfs_set_error(GFS_E_UNSUPPORTED, "world too large");
     if (dims > GFS_MAX_DIMS) return gfs_set_error(GFS_E_UNSUPPORTED, "dimensions must be 1..8");
-    if (cfg->merge_rule > 2 || cfg->payload > 1 || cfg->exchange > 1 || cfg->sharding > 2) return gfs_set_error(GFS_E_ARG, "bad rank config");
+    if (cfg->merge_rule > 3 || cfg->payload > 1 || cfg->exchange > 1 || cfg->sharding > 2) return gfs_set_error(GFS_E_ARG, "bad rank config");
     gfs_rank *r = new (std::nothrow) gfs_rank();
     if (!r) return gfs_set_error(GFS_E_NOMEM, "out of memory");
     r->cfg = *cfg; r->params = *p; r->dims = dims; r->n_nodes = g->n_nodes;
@@ -347,6 +352,13 @@ int gfs_rank_create(const gfs_graph_view *g, const gfs_sgd_params *p, uint64_t d
     int rc = GFS_OK;
     auto bail = [&](int code) { gfs_rank_destroy(r); return code; };
 
+    {   // merge rule 3: the schedule, and the scale of a short-range term (mean node length in bp)
+        r->etas.assign(p->iter_max + 1, 0.0);
+        gfs_sgd_schedule(p, r->etas.data());
+        long double bp = 0; for (uint64_t k = 0; k < g->n_nodes; ++k) bp += g->node_len[k];
+        r->eta_sum = g->n_nodes ? std::max<double>(1.0, (double)(bp / (long double)g->n_nodes)) : 1.0;
+        if (const char *e = std::getenv("GFS_DBG_MERGE_ETA_FACTOR")) { const double f = std::atof(e); if (f > 0.0) r->eta_sum *= f; }   // probe knob
+    }
     // plan: owners, quotas, shared layout, spans
     std::vector<uint32_t> owner(std::max<uint64_t>(g->n_paths, 1));
     r->rank_steps.assign(W, 0); r->quotas.assign(W, 0); r->span_lo.assign(W, 0); r->span_hi.assign(W, 0);
@@ -506,6 +518,7 @@ int gfs_rank_get_positions(gfs_rank *r, double *host, uint64_t n) {
 int gfs_rank_window_begin(gfs_rank *r, const uint64_t *ks, uint64_t n, void *hip_stream) {
     if (!r || (!ks && n)) return gfs_set_error(GFS_E_ARG, "null argument");
     hipStream_t st = (hipStream_t)hip_stream;
+    if (n) { r->win_last_k = ks[n - 1]; r->win_len = n; }
     if (!r->idle && n) {
         const int rc = gfs_ctx_run_range(r->ctx, ks, n, hip_stream);
         if (rc < 0) return rc;
@@ -531,12 +544,22 @@ int gfs_rank_window_end(gfs_rank *r, void *hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     MHIPCHK(hipSetDevice(r->cfg.device));
     double *x = (double *)gfs_ctx_positions_device(r->ctx);
-    const double div = r->cfg.merge_rule == 0 ? 0.0 : (r->cfg.merge_rule == 1 ? 1.0 : (double)r->cfg.world);
+    const double div = (r->cfg.merge_rule == 0 || r->cfg.merge_rule == 3) ? 0.0 : (r->cfg.merge_rule == 1 ? 1.0 : (double)r->cfg.world);
+    // Rule 3 (annealed).  c ranks each ran their share of the window on their own replica.  While the learning rate is large a
+    // term is a FULL correction of its pair (mu = min(eta / d, 1) = 1): c replicas propose c full corrections of the same error
+    // and only their mean is safe (rule 0; their sum diverges).  Once eta is below the distance of even the shortest terms every
+    // move is a small step (mu << 1) and the steps of all ranks ADD, as they do on one shared vector — averaging them throws
+    // away (c - 1)/c of the window's work exactly where the layout is being finished: 8 ranks under rule 0 left the 525k-node
+    // bubble graph at 1.47x the single-GPU error at path distance 1 (profiles/r03/virtual_cluster_touch_rule.log).  The divisor
+    // therefore falls from c to 1 with eta: max(1, c * min(1, window length * eta / mean node length)).
+    double cscale = 1.0;
+    if (r->cfg.merge_rule == 3 && r->win_last_k < r->etas.size())
+        cscale = std::min(1.0, (double)r->win_len * r->etas[r->win_last_k] / r->eta_sum);
     MHIPCHK(hipEventRecord(r->ev[2], st));
     if (r->cfg.payload) hipLaunchKernelGGL((gfs::exchange_apply_kernel<double>), dim3(1024), dim3(256), 0, st, x, r->d_xprev,
-                                           (const double *)r->d_buf, r->d_esegs, (uint32_t)r->esegs.size(), r->total, div);
+                                           (const double *)r->d_buf, r->d_esegs, (uint32_t)r->esegs.size(), r->total, div, cscale);
     else hipLaunchKernelGGL((gfs::exchange_apply_kernel<float>), dim3(1024), dim3(256), 0, st, x, r->d_xprev, (const float *)r->d_buf,
-                            r->d_esegs, (uint32_t)r->esegs.size(), r->total, div);
+                            r->d_esegs, (uint32_t)r->esegs.size(), r->total, div, cscale);
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipEventRecord(r->ev[3], st));
     r->ev_pending = true;

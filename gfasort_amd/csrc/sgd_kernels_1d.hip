@@ -22,31 +22,28 @@ __device__ __forceinline__ bool ref_sample_1d(const KArgs &a, const uint4 *path_
     return t.i != 0xFFFFFFFFu && t.j != 0xFFFFFFFFu;                                   // :525-538
 }
 
-// The worker loop for `quota` successful updates.  Sampling reads no positions, so the NEXT term is sampled — its two
-// dependent record loads — while the position loads of the current one are in flight: a stream is a serial chain of
-// memory round trips and this takes the sampler's two off the chain.  The random numbers are drawn in the reference's
-// order (a term's draws, then the next term's), the terms are applied in the order they were drawn, and no term is
-// sampled that the quota would not apply: one stream is bit for bit the oracle's, with or without the overlap.
+// The worker loop for `quota` successful updates (sgd.rs:442-584).
+// (Round 3 tried sampling the NEXT term while the position loads of the current one are in flight — sampling reads no
+// positions, and one stream stays bit for bit the oracle's.  It bought nothing: vmcnt counts in order on gfx9, so the first
+// load issued after a term's two adds waits for those adds to complete at the memory side (~1.5 us) whatever else overlaps,
+// and that wait, not the sampler's two record loads, is what a stream's 3.5 us per update are made of
+// (profiles/r03/ref_fused_probe.log).  And it cost: a term's positions were read ~1 us earlier before its adds, i.e. more
+// terms in flight per stream, which is what the streams-per-node bound exists to limit — a graph of tandem repeats that is
+// stable at that bound diverged.  Dropped.)
 template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ void ref_run_1d(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng,
                                            const uint32_t quota, const uint64_t max_att, const uint32_t tid,
                                            uint32_t &done, uint32_t &att, uint32_t &ntr) {
     double *x = a.x;
     uint32_t d = 0; uint64_t t = 0;
-    RefTerm1D cur = {0u, 0u, 0, 0.0}, nxt = {0u, 0u, 0, 0.0};
-    bool have = false;
-    while (d < quota && (have || t < max_att)) {
-        if (!have) {
-            ++t;
-            if (!ref_sample_1d<LDS_TABLES>(a, path_tab, zeta_tab, rng, cur)) continue;
-        }
-        double xi, xj;
-        if (a.dbg & 2u) { xi = (double)cur.i; xj = (double)cur.j; }                    // ablation: no position loads
-        else { xi = load_pos<ATOMIC_LOADS>(x + cur.i); xj = load_pos<ATOMIC_LOADS>(x + cur.j); }   // :541-542
-        have = false;
-        if (d + 1u < quota && t < max_att) { ++t; have = ref_sample_1d<LDS_TABLES>(a, path_tab, zeta_tab, rng, nxt); }
+    while (d < quota && t < max_att) {
+        ++t;
+        RefTerm1D cur;
+        if (!ref_sample_1d<LDS_TABLES>(a, path_tab, zeta_tab, rng, cur)) continue;
         const double mu = crowd_scale(fmin(a.it.eta * (1.0 / cur.term_dist), 1.0), cur.crowd);   // :518-520
-        double dx = xi - xj;                                                           // :543
+        double dx;
+        if (a.dbg & 2u) dx = (double)cur.i - (double)cur.j;                            // ablation: no position loads
+        else dx = load_pos<ATOMIC_LOADS>(x + cur.i) - load_pos<ATOMIC_LOADS>(x + cur.j);   // :541-543
         if (dx == 0.0) dx = 1e-9;                                                      // :546-548
         const double mag = fabs(dx);                                                   // :551
         const double delta = mu * (mag - cur.term_dist) / 2.0;                         // :552
@@ -65,7 +62,6 @@ __device__ __forceinline__ void ref_run_1d(const KArgs &a, const uint4 *path_tab
                 ++ntr;
             }
         }
-        if (have) cur = nxt;
     }
     done += d;
     att += t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;

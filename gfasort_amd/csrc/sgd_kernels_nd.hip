@@ -41,35 +41,26 @@ __device__ __forceinline__ bool ref_sample_nd(const KArgs &a, const uint4 *path_
     return t.ni != 0xFFFFFFFFu && t.nj != 0xFFFFFFFFu;                                 // :1089-1096
 }
 
-// The worker loop for `quota` successful updates; as in K1 (sgd_kernels_1d.hip ref_run_1d) the next term is sampled
-// while the coordinate loads of the current one are in flight, in the reference's order of random draws.
+// The worker loop for `quota` successful updates (sgd.rs:988-1156).
 template <int D, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ void ref_run_nd(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng,
                                            const uint32_t quota, const uint64_t max_att, const uint32_t tid,
                                            uint32_t &done, uint32_t &att, uint32_t &ntr) {
     uint32_t d = 0; uint64_t t = 0;
-    RefTermND cur = {0u, 0u, 0u, 0, 0.0}, nxt = {0u, 0u, 0u, 0, 0.0};
-    bool have = false;
-    while (d < quota && (have || t < max_att)) {
-        if (!have) {
-            ++t;
-            if (!ref_sample_nd<LDS_TABLES>(a, path_tab, zeta_tab, rng, cur)) continue;
-        }
+    while (d < quota && t < max_att) {
+        ++t;
+        RefTermND cur;
+        if (!ref_sample_nd<LDS_TABLES>(a, path_tab, zeta_tab, rng, cur)) continue;
         const bool oa = (cur.ends & 1u) != 0u, ob = (cur.ends & 2u) != 0u;
         const uint64_t idx_i = (uint64_t)cur.ni * 2u + (oa ? 1u : 0u);                 // :1099-1103
         const uint64_t idx_j = (uint64_t)cur.nj * 2u + (ob ? 1u : 0u);
         double *ci = coord_ptr<D>(a, cur.ni, oa), *cj = coord_ptr<D>(a, cur.nj, ob);
-        double vi[D], vj[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) { vi[k] = load_pos<ATOMIC_LOADS>(ci + k); vj[k] = load_pos<ATOMIC_LOADS>(cj + k); }   // :1108-1111
-        have = false;
-        if (d + 1u < quota && t < max_att) { ++t; have = ref_sample_nd<LDS_TABLES>(a, path_tab, zeta_tab, rng, nxt); }
         const double mu = crowd_scale(fmin(a.it.eta * (1.0 / cur.term_dist), 1.0), cur.crowd);   // :1085-1086
         double deltas[D];
         double mag_sq = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {                                                  // :1108-1113
-            deltas[k] = vi[k] - vj[k];
+            deltas[k] = load_pos<ATOMIC_LOADS>(ci + k) - load_pos<ATOMIC_LOADS>(cj + k);
             mag_sq += deltas[k] * deltas[k];
         }
         if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }                       // :1116-1119
@@ -92,7 +83,6 @@ __device__ __forceinline__ void ref_run_nd(const KArgs &a, const uint4 *path_tab
                 ++ntr;
             }
         }
-        if (have) cur = nxt;
     }
     done += d;
     att += t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;

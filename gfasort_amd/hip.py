@@ -79,7 +79,7 @@ class RankInfo(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
-MERGE_RULES = {"touch": 0, "sum": 1, "mean": 2}
+MERGE_RULES = {"touch": 0, "sum": 1, "mean": 2, "anneal": 3}
 
 TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)
 

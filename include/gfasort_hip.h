@@ -102,12 +102,15 @@ typedef struct gfs_launch_config {
  * stream and take n consecutive steps of the path with the same signed jump (nD, D <= 3: and the same
  * pair of end flips), so that record loads, position loads and atomics of a bundle coalesce into a
  * few 64-B requests (gfasort_amd/csrc/sgd_device.h).  n = 1: reference streams, every lane is a
- * reference worker thread.  n = 0 (default): the library picks by graph size — 1 for small
- * graphs (< 16384 nodes), else up to 64 while an iteration still has >= 4096 independent draws. */
+ * reference worker thread.  n = 0 (default): the library picks — 1 for graphs of < 16384 nodes, else the widest
+ * bundle (64, 32, ...) for which >= 95 % of the steps lie in paths of at least 4 n steps (measured basis:
+ * profiles/r03/policy_sweep.log).  On graphs whose haplotypes disagree by kilobases the bundled sampler needs a longer
+ * schedule than the reference's to reach the same quality (tests/test_gpu_quality.py). */
 #define GFS_F_BUNDLE(n) (((uint32_t)(n) & 0xFFu) << 16)  /* n in {0 = auto, 1, 4, 8, 16, 32, 64} */
 /* Long runs: with bundles of 64 a sampled (step a, jump) is expanded over k consecutive trips of its wave, i.e. over
  * 64*k consecutive steps (k adapts downwards on short paths).  k = 0 (default): 64 for the 1D sort, 16 for the layout
- * kernels.  k = 1: a run is one trip. */
+ * kernels, less where an iteration would otherwise draw fewer than 64 leaders (a leader stands for up to 64 * k * partners
+ * terms).  k = 1: a run is one trip. */
 #define GFS_F_CHAIN(k) (((uint32_t)(k) & 0xFFu) << 24)   /* k in {0 = auto, 1, 2, 4, 8, 16, 32, 64} */
 #define GFS_F_NO_FUSE       4u        /* gfs_ctx_run / gfs_ctx_run_range: one launch per iteration even where
                                          a fused persistent launch is possible                        */

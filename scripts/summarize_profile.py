@@ -70,7 +70,7 @@ def main():
             vals = [disp[i] for i in sorted(disp)]
             fused = "fused" in k
             if fused:
-                its = [args.steps] * len(vals)          # bench.py: the untimed priming launch and the timed launch, both of --steps iterations
+                its = [args.steps] * len(vals)          # bench.py: the timed launch (and, with --priming, an untimed one of the same shape): --steps iterations each
             else:
                 its = [1] * len(vals)
             mean = sum(vals) / len(vals)
@@ -102,6 +102,10 @@ def main():
             "hbm_bytes_per_update": hbm / args.updates,
             "algorithmic_bytes_per_update": 64,
         }
+        # requests that reached the memory-side atomic units (what binds the team kernels), same passes
+        atom = [per_iter[(kk, c)] for (kk, c) in per_iter if kk == k and c.startswith("TCC_EA0_ATOMIC")]
+        if atom:
+            out["atomic_requests_per_update"] = atom[0] / args.updates
         root = os.path.dirname(os.path.dirname(os.path.abspath(args.dst_prefix)))
         with open(os.path.join(root, "traffic_latest.json"), "w") as fh:
             json.dump(out, fh, indent=1)

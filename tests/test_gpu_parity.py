@@ -343,34 +343,73 @@ def test_bundled_terms_are_node_disjoint_within_a_bundle():
 
 
 def test_auto_bundle_policy():
+    """What the library picks by itself (capi.hip choose_bundle; measured basis: profiles/r03/policy_sweep.log)."""
     g_small = load("DRB1-3123.gfa")
     rc, x, st = hip.path_linear_sgd_raw(g_small, _ygs(g_small, 2))
-    assert st.bundle == 1                                            # small graph: reference streams
-    g_mid = G.synth_bubbles(20000, 16, 5)                            # 26k nodes, 325k steps: 5078 leader draws at B = 64
+    assert st.bundle == 1                                            # < 16384 nodes: reference streams
+    g_mid = G.synth_bubbles(20000, 16, 5)                            # 26k nodes, 325k steps
     rc, x, st = hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2))
-    assert st.bundle == 64
-    g_w = G.synth_windows(50_000, 8, 25_000, 6)                      # 200k steps: 3125 draws at 64, 6250 at 32
+    assert st.bundle == 64 and st.run_trips == 32                    # runs capped so that an iteration draws >= 64 leaders
+    g_w = G.synth_windows(50_000, 8, 25_000, 6)                      # 200k steps in 8 long paths
     rc, x, st = hip.path_linear_sgd_raw(g_w, _ygs(g_w, 2))
-    assert st.bundle == 32
+    assert st.bundle == 64 and st.run_trips == 16
+    g_s = G.synth_windows(40_000, 400, 200, 6)                       # paths of 200 steps: too short for runs of 64
+    rc, x, st = hip.path_linear_sgd_raw(g_s, _ygs(g_s, 2))
+    assert st.bundle == 32 and st.run_trips == 1
+    rc, x, st = hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2), cfg=hip.make_config(flags=hip.F_BUNDLE(64)))
+    assert st.bundle == 64 and st.run_trips == 64                    # an explicit bundle keeps the nominal run length
     rc, x, st = hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2), cfg=hip.make_config(n_streams=1))
     assert st.bundle == 1                                            # a single stream is always a reference stream
     with pytest.raises(hip.GfsError):
         hip.path_linear_sgd_raw(g_mid, _ygs(g_mid, 2), cfg=hip.make_config(n_streams=100, flags=hip.F_BUNDLE(8)))
 
 
+@pytest.mark.parametrize("n_sites,haps", [(12_500, 12), (25_000, 12)])
+def test_auto_policy_at_the_transition_sizes_matches_reference_streams(n_sites, haps):
+    """The smallest graphs the auto policy gives to the team kernel (16.4k and 32.8k nodes), all-default flags against
+    reference streams at equal update counts, three seeds each: relative error per octave of path distance (distance 1 and
+    2-3 over all pairs) within 8 %, sampled stress (1M pairs) within 6 %."""
+    from gfasort_amd import quality as Q
+    g = G.synth_bubbles(n_sites, haps, 11)
+    ctx = hip.Context(g)
+    prof, stress = {}, {}
+    for name, flags in (("default", 0), ("reference", hip.F_BUNDLE(1))):
+        ps, ss = [], []
+        for k in range(3):
+            p = _ygs(g, 100)
+            p.seed = 9399220 + 1000 * k
+            ctx.setup_1d(p, hip.make_config(flags=flags))
+            ctx.init_positions()
+            ctx.run()
+            st = ctx.stats()
+            assert st.bundle == (64 if name == "default" else 1)
+            x = ctx.download()
+            ps.append(Q.stress_by_scale(g, x, 0, 600_000)[1])
+            ss.append(Q.sampled_stress(g, x, 0, 1_000_000))
+        prof[name], stress[name] = np.mean(ps, axis=0), float(np.mean(ss))
+    ctx.close()
+    ratio = prof["default"] / prof["reference"]
+    assert ratio.max() <= 1.08, np.round(ratio, 3).tolist()
+    assert stress["default"] <= 1.06 * stress["reference"], stress
+
+
 @pytest.mark.parametrize("B", [16, 64])
 def test_bundled_quality_matches_reference_streams_on_bubble_graph(B):
-    """P2: pangenome-like graph (SNP bubbles + insertions, 16 haplotypes): sampled stress of the bundled
-    sampler within 10 % of reference streams at equal update counts."""
+    """P2: pangenome-like graph (SNP bubbles + insertions, 16 haplotypes), explicit bundles: relative error per octave of path
+    distance against reference streams at equal update counts.  (B = 16 is the narrow form the auto policy no longer picks on
+    such graphs: its runs of one trip cost the octaves 8-63 up to 10 % here, 40 % at 300k nodes.)"""
+    from gfasort_amd import quality as Q
     g = G.synth_bubbles(20000, 16, 5)
     p = _ygs(g, 100)
     og = oracle_graph(g)
     s0 = O.stress_1d(og, O.init_positions(og), 100000)
     rc, x1, st1 = hip.path_linear_sgd_raw(g, p, cfg=hip.make_config(flags=hip.F_BUNDLE(1)))
     rc, xb, stb = hip.path_linear_sgd_raw(g, p, cfg=hip.make_config(flags=hip.F_BUNDLE(B)))
-    s1, sb = O.stress_1d(og, x1, 100000), O.stress_1d(og, xb, 100000)
     assert st1.term_updates == stb.term_updates == 101 * p.min_term_updates
-    assert s1 < 0.05 * s0 and abs(sb - s1) < 0.10 * s1 + 1e-4, (s0, s1, sb)
+    s1, sb = O.stress_1d(og, x1, 1_000_000), O.stress_1d(og, xb, 1_000_000)
+    ratio = Q.stress_by_scale(g, xb, 0, 600_000)[1] / Q.stress_by_scale(g, x1, 0, 600_000)[1]
+    assert s1 < 0.05 * s0 and sb <= 1.10 * s1, (s0, s1, sb)
+    assert ratio.max() <= (1.15 if B == 16 else 1.08), np.round(ratio, 3).tolist()
 
 
 @pytest.mark.parametrize("B,dims", [(8, 2), (64, 2), (16, 3)])
@@ -402,19 +441,23 @@ def test_bundled_nd_sampler_trace_matches_oracle_mirror(B, dims):
 
 
 def test_bundled_nd_quality_matches_reference_streams():
-    from gfasort_amd import sgd as S
+    """The layout team kernels on a 26k-node bubble graph against reference streams: layout stress (1M pairs) and the relative
+    error per octave of path distance (the large-graph tests of the default are in tests/test_gpu_quality.py)."""
+    from gfasort_amd import sgd as S, quality as Q
     g = G.synth_bubbles(20000, 16, 5)
     p = P.LayoutSGDParams.from_graph(g, 2, 1)
     og = oracle_graph(g)
     c0 = S.default_layout_init(g, 2, p.seed)
-    res = {}
+    res, prof = {}, {}
     for B in (1, 16, 64):
         rc, c, st = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(flags=hip.F_BUNDLE(B)))
         assert rc == 0 and st.bundle == B and st.term_updates == 31 * p.min_term_updates
-        res[B] = O.layout_stress(og, 2, c, 100000)
+        res[B] = O.layout_stress(og, 2, c, 1_000_000)
+        prof[B] = Q.stress_by_scale(g, c, 2, 600_000)[1]
     s0 = O.layout_stress(og, 2, c0, 100000)
     assert res[1] < 0.1 * s0
-    assert abs(res[16] - res[1]) < 0.15 * res[1] + 1e-3 and abs(res[64] - res[1]) < 0.15 * res[1] + 1e-3, (s0, res)
+    assert res[16] <= 1.10 * res[1] and res[64] <= 1.10 * res[1], (s0, res)
+    assert (prof[64] / prof[1]).max() <= 1.10 and (prof[16] / prof[1]).max() <= 1.20, (np.round(prof[64] / prof[1], 3), np.round(prof[16] / prof[1], 3))
 
 
 def test_internal_node_layout_is_path_order_and_invisible():
