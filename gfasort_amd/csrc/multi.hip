@@ -67,8 +67,8 @@ __global__ void exchange_prepare_kernel(const double *x, const double *x_prev, T
         buf[total + e] = d != 0.0 ? (T)1 : (T)0;
     }
 }
-// x_prev += sum_delta / divisor; x = x_prev.  rule 0: divisor = max(1, ranks that moved the node); 1: 1; 2: world;
-// 3: max(1, ranks that moved the node x cscale), cscale in (0, 1] falling with the window's learning rate (gfs_rank_window_end)
+// x_prev += sum_delta / divisor; x = x_prev.  rule 3: divisor = max(1, ranks that moved the node); 1: 1; 2: world;
+// 0: max(1, ranks that moved the node x cscale), cscale in (0, 1] falling with the window's learning rate (gfs_rank_window_end)
 template <typename T>
 __global__ void exchange_apply_kernel(double *x, double *x_prev, const T *buf, const ESeg *segs, uint32_t n_segs, uint64_t total,
                                       double divide_all_by, double cscale) {
@@ -316,8 +316,8 @@ struct gfs_rank {
     double *d_full = nullptr;            // finish: full-length scratch when the caller binds none
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double merge_ms = 0.0; uint64_t windows = 0; bool ev_pending = false;
-    std::vector<double> etas;            // the schedule (merge rule 3)
-    double eta_sum = 1.0;                // learning rate below which a window's moves are small enough to be summed (merge rule 3)
+    std::vector<double> etas;            // the schedule (merge rule 0)
+    double eta_sum = 1.0;                // learning rate below which a window's moves are small enough to be summed (merge rule 0)
     uint64_t win_last_k = 0, win_len = 1;
 };
 
@@ -352,7 +352,7 @@ int gfs_rank_create(const gfs_graph_view *g, const gfs_sgd_params *p, uint64_t d
     int rc = GFS_OK;
     auto bail = [&](int code) { gfs_rank_destroy(r); return code; };
 
-    {   // merge rule 3: the schedule, and the scale of a short-range term (mean node length in bp)
+    {   // merge rule 0: the schedule, and the scale of a short-range term (mean node length in bp)
         r->etas.assign(p->iter_max + 1, 0.0);
         gfs_sgd_schedule(p, r->etas.data());
         long double bp = 0; for (uint64_t k = 0; k < g->n_nodes; ++k) bp += g->node_len[k];
@@ -544,16 +544,16 @@ int gfs_rank_window_end(gfs_rank *r, void *hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     MHIPCHK(hipSetDevice(r->cfg.device));
     double *x = (double *)gfs_ctx_positions_device(r->ctx);
-    const double div = (r->cfg.merge_rule == 0 || r->cfg.merge_rule == 3) ? 0.0 : (r->cfg.merge_rule == 1 ? 1.0 : (double)r->cfg.world);
-    // Rule 3 (annealed).  c ranks each ran their share of the window on their own replica.  While the learning rate is large a
+    const double div = (r->cfg.merge_rule == 0 || r->cfg.merge_rule == 3) ? 0.0 : (r->cfg.merge_rule == 1 ? 1.0 : (double)r->cfg.world);   // 0 annealed, 3 plain touch
+    // Rule 0 (annealed, the default).  c ranks each ran their share of the window on their own replica.  While the learning rate is large a
     // term is a FULL correction of its pair (mu = min(eta / d, 1) = 1): c replicas propose c full corrections of the same error
-    // and only their mean is safe (rule 0; their sum diverges).  Once eta is below the distance of even the shortest terms every
+    // and only their mean is safe (rule 3, "touch"; their sum diverges).  Once eta is below the distance of even the shortest terms every
     // move is a small step (mu << 1) and the steps of all ranks ADD, as they do on one shared vector — averaging them throws
-    // away (c - 1)/c of the window's work exactly where the layout is being finished: 8 ranks under rule 0 left the 525k-node
+    // away (c - 1)/c of the window's work exactly where the layout is being finished: 8 ranks under rule 3 left the 525k-node
     // bubble graph at 1.47x the single-GPU error at path distance 1 (profiles/r03/virtual_cluster_touch_rule.log).  The divisor
     // therefore falls from c to 1 with eta: max(1, c * min(1, window length * eta / mean node length)).
     double cscale = 1.0;
-    if (r->cfg.merge_rule == 3 && r->win_last_k < r->etas.size())
+    if (r->cfg.merge_rule == 0 && r->win_last_k < r->etas.size())
         cscale = std::min(1.0, (double)r->win_len * r->etas[r->win_last_k] / r->eta_sum);
     MHIPCHK(hipEventRecord(r->ev[2], st));
     if (r->cfg.payload) hipLaunchKernelGGL((gfs::exchange_apply_kernel<double>), dim3(1024), dim3(256), 0, st, x, r->d_xprev,

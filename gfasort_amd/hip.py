@@ -79,7 +79,7 @@ class RankInfo(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
-MERGE_RULES = {"touch": 0, "sum": 1, "mean": 2, "anneal": 3}
+MERGE_RULES = {"anneal": 0, "sum": 1, "mean": 2, "touch": 3}
 
 TERM_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("d_ij", "<f8")], align=True)
 
@@ -314,7 +314,7 @@ class ShardPlan:
 class Rank:
     """gfs_rank: one rank of a multi-device run (its shard's context, the exchange of the shared slots)."""
 
-    def __init__(self, g, p, dims, rank, world, device=0, sharding=0, merge_every=1, merge_rule="touch", payload_f64=False,
+    def __init__(self, g, p, dims, rank, world, device=0, sharding=0, merge_every=1, merge_rule="anneal", payload_f64=False,
                  whole_vector=False, launch=None):
         self.graph, self.params, self.dims = g, p, dims
         v, self._keep = make_view(g)

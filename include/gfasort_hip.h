@@ -250,7 +250,11 @@ typedef struct gfs_rank_config {
     int32_t  device;                  /* HIP device of this rank                                                  */
     uint32_t sharding;                /* 0 auto, 1 consecutive blocks of paths, 2 longest-first bin packing       */
     uint32_t merge_every;             /* iterations per merge window (0 = 1); the last iteration always merges    */
-    uint32_t merge_rule;              /* 0: a slot's summed move / number of ranks that moved it; 1 sum; 2 mean   */
+    uint32_t merge_rule;              /* how a window's moves of a slot are merged over the c ranks that moved it:
+                                         0 (default): summed move / max(1, c * min(1, window length * eta / mean node length)) —
+                                         the mean of the ranks' proposals while the learning rate makes every term a full
+                                         correction, their sum once the moves are small steps (multi.hip gfs_rank_window_end);
+                                         1 sum; 2 mean over all ranks; 3 summed move / c at every learning rate            */
     uint32_t payload;                 /* exchange buffer element type: 0 f32, 1 f64                               */
     uint32_t exchange;                /* 0: only the slots two or more ranks can move; 1: the whole vector        */
     gfs_launch_config launch;         /* per-rank launch shape; term_updates_per_iteration and stream_base are set
