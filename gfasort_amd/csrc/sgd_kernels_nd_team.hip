@@ -99,7 +99,8 @@ __device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, 
 // requests.  Wave-uniform control flow: all lanes take part in the shuffles.
 template <int D>
 __device__ __forceinline__ void issue_adds_regrouped(const int lane, const double (&vA)[D], const double (&vB)[D],
-                                                     const unsigned long long pA, const unsigned long long pB, const int fA, const int fB) {
+                                                     const unsigned long long pA, const unsigned long long pB, const int fA, const int fB,
+                                                     const bool dry = false) {
     constexpr int P = D <= 2 ? 2 : 4;
     const int d = lane & (P - 1);
 #pragma unroll
@@ -113,6 +114,7 @@ __device__ __forceinline__ void issue_adds_regrouped(const int lane, const doubl
         }
         const unsigned long long pa = __shfl(pA, m, 64), pb = __shfl(pB, m, 64);
         const int fa = __shfl(fA, m, 64), fb = __shfl(fB, m, 64);
+        if (dry) { asm volatile("" :: "v"(va), "v"(vb), "v"(pa), "v"(pb), "v"(fa), "v"(fb)); continue; }   // ablation: the shuffles without the adds
         if (d < D) {
             if (fa) add_pos(reinterpret_cast<double *>(pa) + d, va);
             if (fb) add_pos(reinterpret_cast<double *>(pb) + d, vb);
@@ -264,9 +266,10 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
     double ca[D], acc[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { ca[d] = 0.0; acc[d] = 0.0; }
+    const bool no_loads = (a.dbg & 2u) != 0u;                                          // ablation (wrong results): no coordinate loads
     if (node != 0xFFFFFFFFu) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) ca[d] = load_pos<ATOMIC_LOADS>(ptr_a + d);
+        for (int d = 0; d < D; ++d) ca[d] = no_loads ? (double)(node + d) : load_pos<ATOMIC_LOADS>(ptr_a + d);
     }
     // the two partners: position, end, coordinates (all loaded before any add of the trip)
     double pos_p[2], cp[2][D]; double *ptr_p[2]; uint64_t idx_p[2]; uint32_t node_p[2];
@@ -286,7 +289,7 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
         for (int d = 0; d < D; ++d) cp[p][d] = 0.0;
         if (rp.x != 0xFFFFFFFFu) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) cp[p][d] = load_pos<ATOMIC_LOADS>(ptr_p[p] + d);
+            for (int d = 0; d < D; ++d) cp[p][d] = no_loads ? (double)(rp.x + 7u * d) : load_pos<ATOMIC_LOADS>(ptr_p[p] + d);
         }
     }
     bool touched = false, second = true;
@@ -334,11 +337,12 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
     }
     if (!(a.dbg & 1u)) {
         // the adds, re-dealt (issue_adds_regrouped): a's end and b's end, then c's end
-        issue_adds_regrouped<D>(lane, acc, rr[0], (unsigned long long)ptr_a, (unsigned long long)ptr_p[0], (int)touched, fadd[0]);
+        const bool dry = (a.dbg2 & 1u) != 0u;
+        issue_adds_regrouped<D>(lane, acc, rr[0], (unsigned long long)ptr_a, (unsigned long long)ptr_p[0], (int)touched, fadd[0], dry);
         double none[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) none[d] = 0.0;
-        issue_adds_regrouped<D>(lane, rr[1], none, (unsigned long long)ptr_p[1], (unsigned long long)ptr_p[1], fadd[1], 0);
+        issue_adds_regrouped<D>(lane, rr[1], none, (unsigned long long)ptr_p[1], (unsigned long long)ptr_p[1], fadd[1], 0, dry);
     }
     return second;
 }
