@@ -97,27 +97,37 @@ __device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, 
 // re-dealt so that a group of P = 2 (D=2) or 4 (D=3) adjacent lanes of one instruction carries the D coordinates of the
 // SAME end: one instruction then covers 64/P neighbouring nodes = 512 (384 for D=3) contiguous bytes = 8-9 (6-7)
 // requests.  Wave-uniform control flow: all lanes take part in the shuffles.
-template <int D>
+// (The flag of an add travels in bit 0 of its 8-byte aligned pointer, and a call that has no second add — HAS_B false —
+// shuffles nothing for it: 6 or 12 lane permutes per pass where round 2 spent 14.  Measured neutral on C4 — the kernel's time is
+// not in these shuffles, profiles/r03/nd_ablate.log — kept because it is less work.)
+__device__ __forceinline__ uint64_t shfl_u64(const uint64_t v, const int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int D, bool HAS_B = true>
 __device__ __forceinline__ void issue_adds_regrouped(const int lane, const double (&vA)[D], const double (&vB)[D],
                                                      const unsigned long long pA, const unsigned long long pB, const int fA, const int fB,
                                                      const bool dry = false) {
     constexpr int P = D <= 2 ? 2 : 4;
     const int d = lane & (P - 1);
+    const unsigned long long tA = pA | (fA ? 1ull : 0ull), tB = pB | (fB ? 1ull : 0ull);
 #pragma unroll
     for (int pass = 0; pass < P; ++pass) {
         const int m = pass * (64 / P) + lane / P;
         double va = 0.0, vb = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            const double ak = __shfl(vA[k], m, 64), bk = __shfl(vB[k], m, 64);
-            if (k == d) { va = ak; vb = bk; }
+            const double ak = __shfl(vA[k], m, 64);
+            if (k == d) va = ak;
+            if (HAS_B) { const double bk = __shfl(vB[k], m, 64); if (k == d) vb = bk; }
         }
-        const unsigned long long pa = __shfl(pA, m, 64), pb = __shfl(pB, m, 64);
-        const int fa = __shfl(fA, m, 64), fb = __shfl(fB, m, 64);
-        if (dry) { asm volatile("" :: "v"(va), "v"(vb), "v"(pa), "v"(pb), "v"(fa), "v"(fb)); continue; }   // ablation: the shuffles without the adds
+        const unsigned long long pa = shfl_u64(tA, m);
+        unsigned long long pb = 0ull;
+        if (HAS_B) pb = shfl_u64(tB, m);
+        if (dry) { asm volatile("" :: "v"(va), "v"(vb), "v"(pa), "v"(pb)); continue; }   // ablation: the shuffles without the adds
         if (d < D) {
-            if (fa) add_pos(reinterpret_cast<double *>(pa) + d, va);
-            if (fb) add_pos(reinterpret_cast<double *>(pb) + d, vb);
+            if (pa & 1ull) add_pos(reinterpret_cast<double *>(pa & ~7ull) + d, va);
+            if (HAS_B && (pb & 1ull)) add_pos(reinterpret_cast<double *>(pb & ~7ull) + d, vb);
         }
     }
 }
@@ -342,7 +352,7 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
         double none[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) none[d] = 0.0;
-        issue_adds_regrouped<D>(lane, rr[1], none, (unsigned long long)ptr_p[1], (unsigned long long)ptr_p[1], fadd[1], 0, dry);
+        issue_adds_regrouped<D, false>(lane, rr[1], none, (unsigned long long)ptr_p[1], 0ull, fadd[1], 0, dry);
     }
     return second;
 }

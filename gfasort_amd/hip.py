@@ -111,7 +111,7 @@ def lib():
     """Load libgfasort_hip.so; raises (never falls back) when it is not built."""
     global _lib
     if _lib is None:
-        path = _build.LIB
+        path = os.environ.get("GFS_LIB_PATH") or _build.LIB      # (GFS_LIB_PATH: experiment builds, scripts/ only)
         if not os.path.exists(path):
             raise ImportError(f"{path} is not built: run `python -m gfasort_amd.build` "
                               "(hipcc, gfx950). There is no CPU fallback.")

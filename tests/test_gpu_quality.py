@@ -37,7 +37,7 @@ def _compare(g, og, x_ref, x_new, what, tol_stress=0.10, tol_octave=0.12):
     assert s_new <= (1.0 + tol_stress) * s_ref, (what, "sampled stress", s_ref, s_new)
     pr, pn = _profile(g, x_ref), _profile(g, x_new)
     worst = float(np.max(pn / pr))
-    assert worst <= 1.0 + tol_octave, (what, "relative error by octave of path distance", np.round(pn / pr, 3).tolist())
+    assert worst <= 1.0 + tol_octave, (what, "relative error by octave of path distance", " ".join(f"{v:.3f}" for v in pn / pr))
     o_ref, o_new = hip.sort_order(x_ref).astype(np.int64), hip.sort_order(x_new).astype(np.int64)
     q_ref, q_new = Q.layout_quality(g, o_ref), Q.layout_quality(g, o_new)
     assert q_new["rmse"] <= 1.05 * q_ref["rmse"] and q_new["mae"] <= 1.05 * q_ref["mae"], (what, q_ref, q_new)
@@ -142,7 +142,7 @@ def _compare_layout(g, og, dims, c_ref, c_new, what, tol_stress=0.10, tol_octave
     assert s_new <= (1.0 + tol_stress) * s_ref, (what, "sampled layout stress", s_ref, s_new)
     pr, pn = _layout_profile(g, c_ref, dims), _layout_profile(g, c_new, dims)
     worst = float(np.max(pn / pr))
-    assert worst <= 1.0 + tol_octave, (what, "relative error by octave of path distance", np.round(pn / pr, 3).tolist())
+    assert worst <= 1.0 + tol_octave, (what, "relative error by octave of path distance", " ".join(f"{v:.3f}" for v in pn / pr))
     (m_ref, a_ref), (m_new, a_new) = _end_to_end(g, c_ref, dims), _end_to_end(g, c_new, dims)
     assert m_new <= 1.10 * m_ref + 0.02 and a_new <= 1.10 * a_ref + 0.02, (what, "node end-to-end distance vs length", (m_ref, a_ref), (m_new, a_new))
     return dict(stress=(s_ref, s_new), worst_octave=worst, end_to_end=((m_ref, a_ref), (m_new, a_new)))
