@@ -482,7 +482,9 @@ __device__ __forceinline__ void load_pass(const KArgs &a, uint32_t tid, TeamStat
     const uint32_t w = a.lead[5 * T + tid];
     ts.L.ra1 = a.lead[6 * T + tid]; ts.L.rb1 = a.lead[7 * T + tid];
     ts.L.ok = (w & 0xFFu) | ((w >> 27) << 8);
-    ts.left = (w >> 8) & 0xFFu; ts.cool = (w >> 16) & 1u; ts.colour = (w >> 17) & 1u; ts.seg = (w >> 18) & 0xFFu; ts.p = (w >> 26) & 1u;
+    // (the place in the pass is the same for all 64 lanes of the wave: scalar registers)
+    const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    ts.left = (ws >> 8) & 0xFFu; ts.cool = (ws >> 16) & 1u; ts.colour = (ws >> 17) & 1u; ts.seg = (ws >> 18) & 0xFFu; ts.p = (ws >> 26) & 1u;
 }
 __device__ __forceinline__ void store_pass(const KArgs &a, uint32_t tid, const TeamState &ts) {
     if (!a.lead) return;
@@ -546,9 +548,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_kernel(con
 // iteration still applies exactly min_term_updates updates with its own eta/theta.  C3: 97.8 G updates/s.
 // (A single wave claims every chunk itself, in order: the kernel with fixed quotas works through its quota in the same
 // chunks, so that one wave is bit for bit the oracle's mirror in both.)
-template <int B, bool LDS_TABLES, bool ATOMIC_LOADS>
+// (POOL is a template parameter so that each build holds ONE inlined copy of the trip machine: with both launch modes in one
+// kernel the pooled path spilled 65 VGPRs into 188 B of scratch per lane — and a first dispatch that needs more scratch than any
+// kernel before it makes the runtime re-size the queue's scratch, the ~0.12 ms "first-dispatch latency" of profiles/r02/launch_gap.log.)
+template <int B, bool LDS_TABLES, bool POOL>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters,
                                                                                    uint32_t *pool) {
+    constexpr bool ATOMIC_LOADS = true;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
     stage_tables<LDS_TABLES>(a0, smem, path_tab, zeta_tab);
@@ -560,8 +566,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_fused_kern
     ts.rng.s0 = a.rng[tid]; ts.rng.s1 = a.rng[T + tid]; ts.rng.s2 = a.rng[2 * T + tid]; ts.rng.s3 = a.rng[3 * T + tid];
     const int lane = threadIdx.x & 63;
     load_pass(a, tid, ts);
-    if (pool) {
-        const uint32_t wave = tid >> 6, n_waves = a0.n_streams >> 6;
+    if (POOL) {
+        const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), n_waves = a0.n_streams >> 6;   // (scalar registers)
         const uint32_t slots = pool_slots(n_waves), slot = wave % slots;
         const uint64_t total = (uint64_t)a0.quota_base * a0.n_streams + a0.quota_rem;
         const uint32_t cap = (uint32_t)(total / slots + (slot < total % slots ? 1u : 0u));   // < 2^31 (host-checked)
@@ -662,8 +668,13 @@ static hipError_t launch_1db(const KArgs &a, bool lds_tables, bool atomic_loads,
 template <int B>
 static hipError_t launch_1d_fused_b(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
                                     uint32_t *pool, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (lds_tables) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, true>), grid, block, lds, st, a, d_its, n_iters, pool);
-    else            hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, true>), grid, block, 0, st, a, d_its, n_iters, pool);
+    if (pool) {
+        if (lds_tables) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, true>), grid, block, lds, st, a, d_its, n_iters, pool);
+        else            hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, true>), grid, block, 0, st, a, d_its, n_iters, pool);
+    } else {                                                           // GFS_F_DBG_FREE_RUNNING: fixed quotas
+        if (lds_tables) hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, true, false>), grid, block, lds, st, a, d_its, n_iters, pool);
+        else            hipLaunchKernelGGL((sgd1d_team_fused_kernel<B, false, false>), grid, block, 0, st, a, d_its, n_iters, pool);
+    }
     return hipGetLastError();
 }
 // fused range of iterations; only for the team kernel with its widest bundles (what the auto policy picks

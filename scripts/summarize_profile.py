@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--updates", type=float, default=1e7, help="term updates per iteration")
     ap.add_argument("--no-traffic", action="store_true", help="do not rewrite profiles/traffic_latest.json")
+    ap.add_argument("--priming", action="store_true", help="bench.py ran with --priming (two launches of --steps iterations)")
     args = ap.parse_args()
 
     newest = lambda files: max(files, key=os.path.getmtime)      # gpurun merges runs: keep the latest
@@ -46,6 +47,29 @@ def main():
             for row in fh:                                       # keep the SGD kernels; drop rocPRIM's kilobyte-long names
                 if row.startswith('"Name"') or "gfs::" in row.split('",')[0]:
                     out.write(row)
+    # every dispatch of the SGD kernels in the timed process, in order (the --stats table only has averages: bench.py's warm-up
+    # steps are one-iteration ranges through the same gfs_ctx_run_range the timed region uses, i.e. dispatches of the same fused
+    # kernel function, so its --stats average mixes W one-iteration launches with the timed launch of --steps iterations)
+    kt = glob.glob(os.path.join(args.src, "trace", "*", "*_kernel_trace.csv"))
+    if kt:
+        pid = lambda f: int(os.path.basename(f).split("_")[0])
+        parent = min(kt, key=pid)
+        rows = []
+        with open(parent) as fh:
+            for r in csv.DictReader(fh):
+                if "gfs::sgd" in r["Kernel_Name"]:
+                    rows.append((int(r["Start_Timestamp"]), short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        rows.sort()
+        with open(args.dst_prefix + "_dispatches.csv", "w") as out:
+            out.write("order,kernel,duration_ns,sgd_iterations\n")
+            n_fused = sum(1 for r in rows if "fused" in r[1])
+            seen = 0
+            for k, (t0, name, dur) in enumerate(rows):
+                its = 1
+                if "fused" in name:
+                    seen += 1
+                    its = args.steps if (seen == n_fused or (args.priming and seen == n_fused - 1)) else 1
+                out.write("%d,\"%s\",%d,%d\n" % (k, name, dur, its))
     bj = os.path.join(args.src, "bench_trace.json")
     if os.path.exists(bj):
         shutil.copy(bj, args.dst_prefix + "_bench_under_rocprof.json")
@@ -70,7 +94,9 @@ def main():
             vals = [disp[i] for i in sorted(disp)]
             fused = "fused" in k
             if fused:
-                its = [args.steps] * len(vals)          # bench.py: the timed launch (and, with --priming, an untimed one of the same shape): --steps iterations each
+                # bench.py: W warm-up ranges of one iteration, then (with --priming: an untimed and) the timed launch of --steps iterations
+                big = 2 if args.priming else 1
+                its = [1] * max(len(vals) - big, 0) + [args.steps] * min(big, len(vals))
             else:
                 its = [1] * len(vals)
             mean = sum(vals) / len(vals)
