@@ -156,10 +156,8 @@ struct Trip {
     uint32_t off = 0;          // wave-uniform: this trip starts `off` steps after the run's first step (run_offset)
 };
 
-template <int B> __device__ __forceinline__ bool scatter_short(const KArgs &, const Leader &, int, uint32_t, uint32_t, uint32_t, int, Trip &);
 template <int B>
 __device__ __forceinline__ void expand_trip(const KArgs &a, const Leader &L, int t, uint32_t seg, uint32_t p, uint32_t colour, int sub, int q, Trip &tr) {
-    if (B == 64 && (a.dbg2 & 12u) && scatter_short<B>(a, L, t, seg, p, colour, sub, tr)) return;
     constexpr int RUNS = 64 / B;
     const int ll = t * RUNS + q;
     const uint32_t okw = bcast<B>(L.ok, ll), cnt = bcast<B>(L.cnt, ll);
@@ -208,36 +206,6 @@ __device__ __forceinline__ void expand_trip(const KArgs &a, const Leader &L, int
     }
     tr.valid = expand_run<B>(ok, first, cnt, ra0, rb0, sub, colour, tr.off, tr.sa, tr.sb);
     if (tr.valid) { tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb]; }
-}
-
-// EXPERIMENT (GFS_DBG2 bit 2, scripts/tiled_short_probe.py): the terms of a short-jump leader (|jump| < 64) scattered
-// independently over the leader's path — every lane its own pseudo-random step, the leader's jump — instead of 64 consecutive
-// steps per trip: the reference's independent terms for the short jumps, at the same number of terms.
-template <int B>
-__device__ __forceinline__ bool scatter_short(const KArgs &a, const Leader &L, int t, uint32_t seg, uint32_t p, uint32_t colour, int sub, Trip &tr) {
-    if (B != 64 || !(a.dbg2 & 12u)) return false;
-    const uint32_t okw = bcast<B>(L.ok, t), cnt = bcast<B>(L.cnt, t);
-    const uint32_t ok = leader_ok(okw, p);
-    const uint32_t ra0 = p ? bcast<B>(L.ra1, t) : bcast<B>(L.ra0, t), rb0 = p ? bcast<B>(L.rb1, t) : bcast<B>(L.rb0, t);
-    const int64_t s = (int64_t)rb0 - (int64_t)ra0;
-    if (!(ok & 1u) || cnt < 256u || s == 0 || s >= 64 || s <= -64) return false;
-    const uint64_t first = bcast_first<B>(L, t);
-    const uint32_t z = (uint32_t)(s < 0 ? -s : s);
-    // bit 2: every lane its own step; bit 3: WINDOWS of 8 consecutive steps (one 64-B line of positions), 8 independent ones per trip
-    const bool win8 = (a.dbg2 & 8u) != 0u;
-    const uint32_t who = win8 ? ((blockIdx.x * blockDim.x + threadIdx.x) >> 3) : (blockIdx.x * blockDim.x + threadIdx.x);
-    uint32_t h = who * 0x9E3779B1u ^ (seg + 1u) * 0x85EBCA6Bu ^ ra0 * 0xC2B2AE35u ^ (p << 7) ^ (uint32_t)t;
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-    const uint32_t l = win8 ? ((uint32_t)sub & 7u) : 0u;
-    const uint32_t base = h % (cnt - z - (win8 ? 7u : 0u)) + l;
-    tr.k = run_trips(a.chain, 64u, cnt); tr.off = 0; tr.mshift = 0; tr.fused = false; tr.twin = false;
-    tr.rc = make_uint4(0, 0, 0, 0);
-    tr.two = win8 && z < 8u;                                          // the window's terms (l, l + z) chain through shared nodes: two colours
-    tr.valid = tr.two ? (((l / z) & 1u) == colour) : colour == 0u;
-    tr.sa = first + base + (s < 0 ? z : 0u); tr.sb = first + base + (s < 0 ? 0u : z);
-    tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb];
-    (void)sub;
-    return true;
 }
 
 // The term arithmetic of sgd.rs:518-571 on values already in registers; returns r_x.
@@ -302,8 +270,6 @@ __device__ __forceinline__ bool fused_trip(const KArgs &a, TeamState &ts, const 
         double r_x = 0.0;
         if (valid) {
             r_x = term_move(a, term_dist, xo, xj, crowd);
-            if (a.dbg2 & 16u) r_x *= 0.5;                                              // EXPERIMENT: under-relaxed sweeps
-            if ((a.dbg2 & 32u) && a.it.cooling) r_x *= 0.5;                            // EXPERIMENT: ... in the cooling half only
             ++ts.done;                                                                 // :579
             if (TRACE) {
                 if (ts.ntr < a.trace_per_stream) {

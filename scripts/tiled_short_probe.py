@@ -1,5 +1,5 @@
 """DRB1-3123 x120, --iter-max 100: is it the SHORT-jump terms' bundling (64 consecutive steps per trip) that makes the team kernel
-fall behind in the cooling half?  GFS_DBG2=4 scatters the terms of short-jump leaders independently over the path (same number
+fall behind in the cooling half?  (code: git history, commit "Experiments on the cooling-phase lag") GFS_DBG2=4 scattered the terms of short-jump leaders independently over the path (same number
 of terms, reference-like); long jumps stay bundled.   python scripts/tiled_short_probe.py"""
 import os
 import sys
