@@ -429,13 +429,12 @@ static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
     // one stream per node and lose it at two (0.224 / 0.248 / 0.220), at 2.0 / 1.65 / 1.2 times the rate
     // (profiles/r02/stream_cap_pools.log; round 1 allowed one per 2 nodes, measured with free-running waves whose drift
     // cost precision by itself).  An explicit n_streams overrides this.
-    // Round 3, with the relative error at distances 1 and 2-3 measured over ALL pairs (profiles/r03/stream_cap_probe.log; bubble
-    // graphs of 66k / 131k / 302k nodes, two seeds per cell, against reference streams): the 1D team kernel keeps every octave
-    // within 4 % up to 1.5 streams per node (distance 1: 1.00 / 0.98 / 0.97 at 1.0, 1.02 / 1.00 / 0.94 at 1.5) and loses
-    // distance 1 at 2.0 (+11...19 %): five streams per 4 nodes now, which runs those graphs at 35.7 / 59.4 G updates/s where
-    // three per 4 ran them at 23.0 / 46.4.  (The layout kernels, and graphs below the measured range, keep three per 4.)
-    const bool five = team && c->dims == 0 && c->n_nodes >= 65536;
-    const uint64_t by_nodes = (team ? (five ? c->n_nodes * 5 / 4 : c->n_nodes * 3 / 4) : c->n_nodes / 4) / 64 * 64;
+    // Round 3 re-measured the bound (medium graphs leave the chip partly empty under it).  Bubble graphs of 66k / 131k / 302k
+    // nodes keep every octave of the relative error within 4 % of reference streams up to 1.5 streams per node and lose distance
+    // 1 at 2.0 (profiles/r03/stream_cap_probe.log) — but a window graph whose 16 paths each cover 5/8 of its 200k nodes loses its
+    // exact chain order at 1.0 per node (3-115 inversions) and is scrambled at 1.25 (profiles/r03/chain_cap_probe.log), where
+    // three per 4 nodes is exact on every graph tried.  The bound stays.
+    const uint64_t by_nodes = (team ? c->n_nodes * 3 / 4 : c->n_nodes / 4) / 64 * 64;
     return std::max<uint64_t>(64, std::min(chip, std::min(by_work, by_nodes)));
 }
 
