@@ -261,6 +261,19 @@ def test_c4_layout_full_size():
     assert np.median(np.abs(d - g.node_len)) < 0.1       # 0.045 with reference streams, 0.064 at B=64
 
 
+@pytest.mark.parametrize("seed", [9399220, 9400220])
+def test_densely_covered_window_graph_sorts_exactly(seed):
+    """windows(200000, 16, 125000): every node lies on ~10 of the 16 paths.  The graph that fixes the team kernel's
+    streams-per-node bound: exact at three streams per 4 nodes, 3-115 inversions at one per node, scrambled at five per 4
+    (profiles/r03/chain_cap_probe.log) — bubble graphs would have allowed 1.5 per node."""
+    g = G.synth_windows(200_000, 16, 125_000, 7)
+    p = P.YgsParams.from_graph(g, 0, 1).path_sgd
+    p.seed = seed
+    rc, x, st = hip.path_linear_sgd_raw(g, p)
+    assert rc == 0 and st.bundle == 64 and st.launches == 1 and st.n_streams <= g.n_nodes * 3 // 4
+    assert _chain_order_ok(g, x)
+
+
 def test_c5_scale_10m_nodes_100m_steps():
     """BASELINE configs[4] on ONE GPU, the whole default `-p Y` run: 10M nodes / 1024 paths / 1e8 steps,
     101 iterations = 1.01e10 updates (0.15 s of kernel time), exact chain order at that size."""
