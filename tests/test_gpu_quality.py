@@ -252,6 +252,31 @@ def test_default_flags_on_drb1_tiled_in_series(shuffle_seed):
     assert Q.kendall_tau(r_ref, r_def) >= 0.99
 
 
+def test_default_layout_flags_on_drb1_tiled_in_series():
+    """`-p L --dimensions 2` on DRB1-3123 x120 (see the test above): the default layout kernel against reference streams from the
+    same start.  As for the sort, the reference's default schedule (--layout-iter 30) does not converge on this graph (relative
+    error 29 at path distance 1 for reference streams) and the run sampler is behind there — milder than in 1D: +12 % at distance
+    1, +9...13 % from 32 steps up (profiles/r03/layout_partner_probe.log; one partner per leader is no different) — and at
+    parity at three times the schedule (profiles/r03/tiled_layout_probe.log)."""
+    from gfasort_amd import sgd as S
+    g = G.tile_series(load("DRB1-3123.gfa"), 120)
+    og = oracle_graph(g)
+    for iters in (90, 30):
+        p = P.LayoutSGDParams.from_graph(g, 2, 1)
+        p.iter_max = iters
+        c0 = S.default_layout_init(g, 2, p.seed)
+        rc, c_def, st = hip.path_linear_sgd_layout_raw(g, p, c0)
+        assert rc == 0 and st.bundle == 64 and st.term_updates == (p.iter_max + 1) * p.min_term_updates
+        rc, c_b1, st1 = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(flags=hip.F_BUNDLE(1)))
+        assert rc == 0 and st1.bundle == 1 and st1.term_updates == st.term_updates
+        if iters == 90:
+            _compare_layout(g, og, 2, c_b1, c_def, "DRB1 x120 --layout-iter 90, default layout flags vs GPU reference streams")
+        else:
+            s_ref, s_def = O.layout_stress(og, 2, c_b1, 2_000_000), O.layout_stress(og, 2, c_def, 2_000_000)
+            ratio = _layout_profile(g, c_def, 2) / _layout_profile(g, c_b1, 2)
+            assert s_def <= 1.12 * s_ref and ratio.max() <= 1.25, (s_ref, s_def, " ".join(f"{v:.3f}" for v in ratio))
+
+
 def test_more_than_4_million_paths():
     """Round 1 kept 22 bits for the path id in a step record (n_paths < 2^22); the crowding exponents now live in the
     spare top bits of the position's high word.  4.3M two-step paths over a chain: exact counts, and the chain sorts."""
