@@ -229,38 +229,41 @@ def _write_gfa(g, path):
             fh.write(f"P\t{name}\t" + ",".join(f"{i}+" for i in g.step_node_id[first[pth]:first[pth + 1]].tolist()) + "\t*\n")
 
 
-def wall_clock_leg(g, pipeline="Y"):
+def wall_clock_legs(g, pipelines=("Y", "L")):
     """The other half of BASELINE's metric: wall-clock of the whole run, GFA text in -> GFA text (and layout TSV) out, through
-    the C++ CLI (gfasort_amd/bin/gfasort_hip): `-p Y --iter-max 200` (configs[2]) or `-p L --dimensions 2` (configs[3],
-    src/bin/gfasort.rs:265-292)."""
+    the C++ CLI (gfasort_amd/bin/gfasort_hip): `-p Y --iter-max 200` (configs[2]) and `-p L --dimensions 2` (configs[3],
+    src/bin/gfasort.rs:265-292).  The input file is written once."""
     import subprocess
     import tempfile
     from gfasort_amd import build as B
     if not os.path.exists(B.CLI):
-        return None
+        return {p: None for p in pipelines}
     d = tempfile.mkdtemp(prefix="gfs_bench_")
     src, dst, tsv = os.path.join(d, "c3.gfa"), os.path.join(d, "c3.out.gfa"), os.path.join(d, "c3.layout.tsv")
     _write_gfa(g, src)
-    cmd = [B.CLI, "-i", src, "-o", dst, "-p", pipeline, "-v", "1"] + \
-          (["--iter-max", "200"] if pipeline == "Y" else ["--dimensions", "2", "--layout-out", tsv])
-    t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    dt = time.perf_counter() - t0
-    phases = [ln for ln in r.stderr.split("\n") if ln.startswith("[gfasort] done")]
-    engine = [ln for ln in r.stderr.split("\n") if ln.startswith("[gfasort_hip]")]
-    out = {"seconds": dt, "returncode": r.returncode, "input_mb": os.path.getsize(src) / 1e6,
-           "command": "gfasort_hip -i c3.gfa -o c3.out.gfa " + " ".join(cmd[5:]).replace(tsv, "c3.layout.tsv"),
-           "phases": phases[0] if phases else "", "engine": engine[0] if engine else ""}
-    if pipeline == "L":
-        out["layout_stress_10k_pairs"] = next((float(ln.split("layout stress:")[1].split()[0]) for ln in r.stderr.split("\n")
-                                               if "layout stress:" in ln), None)
-        out["layout_tsv_mb"] = os.path.getsize(tsv) / 1e6 if os.path.exists(tsv) else None
+    res = {}
+    for pipeline in pipelines:
+        cmd = [B.CLI, "-i", src, "-o", dst, "-p", pipeline, "-v", "1"] + \
+              (["--iter-max", "200"] if pipeline == "Y" else ["--dimensions", "2", "--layout-out", tsv])
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        phases = [ln for ln in r.stderr.split("\n") if ln.startswith("[gfasort] done")]
+        engine = [ln for ln in r.stderr.split("\n") if ln.startswith("[gfasort_hip]")]
+        out = {"seconds": dt, "returncode": r.returncode, "input_mb": os.path.getsize(src) / 1e6,
+               "command": "gfasort_hip -i c3.gfa -o c3.out.gfa " + " ".join(cmd[5:]).replace(tsv, "c3.layout.tsv"),
+               "phases": phases[0] if phases else "", "engine": engine[0] if engine else ""}
+        if pipeline == "L":
+            out["layout_stress_10k_pairs"] = next((float(ln.split("layout stress:")[1].split()[0]) for ln in r.stderr.split("\n")
+                                                   if "layout stress:" in ln), None)
+            out["layout_tsv_mb"] = os.path.getsize(tsv) / 1e6 if os.path.exists(tsv) else None
+        res[pipeline] = out
     for f in (src, dst, tsv):
         try:
             os.remove(f)
         except OSError:
             pass
-    return out
+    return res
 
 
 def run_leg(name, args):
@@ -575,8 +578,8 @@ def main():
             for name in legs:
                 out[name] = run_leg(name, args)
         if world == 1 and not args.no_cpu_baseline:
-            out["wall_clock_pY"] = wall_clock_leg(g, "Y")
-            out["wall_clock_pL"] = wall_clock_leg(g, "L")
+            wc = wall_clock_legs(g)
+            out["wall_clock_pY"], out["wall_clock_pL"] = wc["Y"], wc["L"]
             out["cpu_baseline"] = cpu_baseline(g, p)
         print(json.dumps(out), flush=True)
     if world > 1:
