@@ -183,13 +183,12 @@ __device__ __forceinline__ uint32_t dirty_zipf(const IterConsts &c, uint32_t jum
     return r < jump ? r : jump;                                                        // :149
 }
 
-// One trip of the pair sampler, sgd.rs:444-499 == :990-1037.  Returns false on `continue`.
+// One trip of the pair sampler, sgd.rs:444-499 == :990-1037, from a step a that has been drawn (sgd.rs:444) and whose record
+// has been requested already.  Returns false on `continue`.
 template <bool LDS_TABLES>
-__device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
-                                            Rng &rng, uint4 &ra, uint4 &rb, uint64_t &sa, uint64_t &sb,
-                                            uint32_t &cnt_out, uint32_t &path_out) {
-    const uint64_t step_idx = sample_step(a, rng);                                     // :444
-    ra = a.step_rec[step_idx];
+__device__ __forceinline__ bool sample_pair_from(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
+                                                 Rng &rng, const uint64_t step_idx, const uint4 &ra, uint4 &rb, uint64_t &sa, uint64_t &sb,
+                                                 uint32_t &cnt_out, uint32_t &path_out) {
     uint32_t path = rec_path(ra);                                                      // :445
     uint4 pr = path_tab[path];
     const uint64_t first = path_first(pr); const uint32_t cnt = pr.y;                  // :446
@@ -217,6 +216,14 @@ __device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_ta
     rb = a.step_rec[sb];
     cnt_out = cnt; path_out = path;
     return true;
+}
+template <bool LDS_TABLES>
+__device__ __forceinline__ bool sample_pair(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
+                                            Rng &rng, uint4 &ra, uint4 &rb, uint64_t &sa, uint64_t &sb,
+                                            uint32_t &cnt_out, uint32_t &path_out) {
+    const uint64_t step_idx = sample_step(a, rng);                                     // :444
+    ra = a.step_rec[step_idx];
+    return sample_pair_from<LDS_TABLES>(a, path_tab, zeta_tab, rng, step_idx, ra, rb, sa, sb, cnt_out, path_out);
 }
 
 // ------------------------------------------------------------------------------------------

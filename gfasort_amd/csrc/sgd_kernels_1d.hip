@@ -11,10 +11,12 @@ namespace gfs {
 // sgd.rs:444-538.  Returns false where the reference `continue`s.
 struct RefTerm1D { uint32_t i, j; int crowd; double term_dist; };
 
+// (step_idx, ra: the trip's step a and its record, drawn and requested by the caller — see ref_run_1d)
 template <bool LDS_TABLES>
-__device__ __forceinline__ bool ref_sample_1d(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng, RefTerm1D &t) {
-    uint4 ra, rb; uint64_t sa, sb; uint32_t cnt, path;
-    if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) return false;
+__device__ __forceinline__ bool ref_sample_1d(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng,
+                                              const uint64_t step_idx, const uint4 &ra, RefTerm1D &t) {
+    uint4 rb; uint64_t sa, sb; uint32_t cnt, path;
+    if (!sample_pair_from<LDS_TABLES>(a, path_tab, zeta_tab, rng, step_idx, ra, rb, sa, sb, cnt, path)) return false;
     t.term_dist = fabs(rec_pos(ra) - rec_pos(rb));                                     // sgd.rs:513
     if (t.term_dist == 0.0) return false;                                              // :514
     t.crowd = crowd_shift<false>(a, ra, rb);
@@ -23,23 +25,27 @@ __device__ __forceinline__ bool ref_sample_1d(const KArgs &a, const uint4 *path_
 }
 
 // The worker loop for `quota` successful updates (sgd.rs:442-584).
-// (Round 3 tried sampling the NEXT term while the position loads of the current one are in flight — sampling reads no
-// positions, and one stream stays bit for bit the oracle's.  It bought nothing: vmcnt counts in order on gfx9, so the first
-// load issued after a term's two adds waits for those adds to complete at the memory side (~1.5 us) whatever else overlaps,
-// and that wait, not the sampler's two record loads, is what a stream's 3.5 us per update are made of
-// (profiles/r03/ref_fused_probe.log).  And it cost: a term's positions were read ~1 us earlier before its adds, i.e. more
-// terms in flight per stream, which is what the streams-per-node bound exists to limit — a graph of tandem repeats that is
-// stable at that bound diverged.  Dropped.)
+// ONE thing is moved: the draw of the NEXT trip's step a (sgd.rs:444 — the next random number in the stream's order whatever
+// happens in between) and the request of its record are issued BEFORE the current term's two adds instead of after them.
+// vmcnt counts in order on gfx9: a load issued after the adds cannot be seen to complete before the adds have completed at the
+// memory side (~1.5 us), and that wait was on every update's critical path; a load issued before them can.  Records are
+// read-only, positions are still read after the previous term's adds: one stream is bit for bit the oracle's (tested), and a
+// term is in flight no longer than before.  (Round 3 first overlapped the WHOLE next sample with the position loads: no faster,
+// and a term's positions were then read ~1 us earlier — more terms in flight per stream, which the streams-per-node bound
+// exists to limit: a tandem-repeat graph stable at the bound diverged.  profiles/r03/ref_fused_probe.log, repeat_stability.log.)
 template <bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ void ref_run_1d(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng,
                                            const uint32_t quota, const uint64_t max_att, const uint32_t tid,
                                            uint32_t &done, uint32_t &att, uint32_t &ntr) {
     double *x = a.x;
     uint32_t d = 0; uint64_t t = 0;
+    uint64_t s_a = 0; uint4 r_a = make_uint4(0, 0, 0, 0); bool drawn = false;         // the next trip's step a, when drawn ahead
     while (d < quota && t < max_att) {
         ++t;
+        if (!drawn) { s_a = sample_step(a, rng); r_a = a.step_rec[s_a]; }              // :444
+        drawn = false;
         RefTerm1D cur;
-        if (!ref_sample_1d<LDS_TABLES>(a, path_tab, zeta_tab, rng, cur)) continue;
+        if (!ref_sample_1d<LDS_TABLES>(a, path_tab, zeta_tab, rng, s_a, r_a, cur)) continue;
         const double mu = crowd_scale(fmin(a.it.eta * (1.0 / cur.term_dist), 1.0), cur.crowd);   // :518-520
         double dx;
         if (a.dbg & 2u) dx = (double)cur.i - (double)cur.j;                            // ablation: no position loads
@@ -49,6 +55,7 @@ __device__ __forceinline__ void ref_run_1d(const KArgs &a, const uint4 *path_tab
         const double delta = mu * (mag - cur.term_dist) / 2.0;                         // :552
         const double r = delta / mag;                                                  // :570
         const double r_x = r * dx;                                                     // :571
+        if (d + 1u < quota && t < max_att) { s_a = sample_step(a, rng); r_a = a.step_rec[s_a]; drawn = true; }   // the next trip's :444
         if (a.dbg & 1u) { asm volatile("" :: "v"(r_x)); }                              // ablation: no atomics
         else {
             add_pos(x + cur.i, -r_x);                                                  // :575

@@ -16,9 +16,10 @@ namespace gfs {
 struct RefTermND { uint32_t ni, nj; uint32_t ends; int crowd; double term_dist; };     // ends: bit 0 = end of i, bit 1 = end of j
 
 template <bool LDS_TABLES>
-__device__ __forceinline__ bool ref_sample_nd(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng, RefTermND &t) {
-    uint4 ra, rb; uint64_t sa, sb; uint32_t cnt, path;
-    if (!sample_pair<LDS_TABLES>(a, path_tab, zeta_tab, rng, ra, rb, sa, sb, cnt, path)) return false;
+__device__ __forceinline__ bool ref_sample_nd(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng,
+                                              const uint64_t step_idx, const uint4 &ra, RefTermND &t) {
+    uint4 rb; uint64_t sa, sb; uint32_t cnt, path;
+    if (!sample_pair_from<LDS_TABLES>(a, path_tab, zeta_tab, rng, step_idx, ra, rb, sa, sb, cnt, path)) return false;
     const uint64_t first = path_first(path_tab[path]);
     const uint64_t last_step = first + cnt - 1u;
     const uint64_t plen = a.path_len[path];
@@ -41,16 +42,20 @@ __device__ __forceinline__ bool ref_sample_nd(const KArgs &a, const uint4 *path_
     return t.ni != 0xFFFFFFFFu && t.nj != 0xFFFFFFFFu;                                 // :1089-1096
 }
 
-// The worker loop for `quota` successful updates (sgd.rs:988-1156).
+// The worker loop for `quota` successful updates (sgd.rs:988-1156).  As in K1 (sgd_kernels_1d.hip ref_run_1d) the next trip's
+// step a is drawn, and its record requested, before the current term's adds are issued.
 template <int D, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ void ref_run_nd(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, Rng &rng,
                                            const uint32_t quota, const uint64_t max_att, const uint32_t tid,
                                            uint32_t &done, uint32_t &att, uint32_t &ntr) {
     uint32_t d = 0; uint64_t t = 0;
+    uint64_t s_a = 0; uint4 r_a = make_uint4(0, 0, 0, 0); bool drawn = false;         // the next trip's step a, when drawn ahead
     while (d < quota && t < max_att) {
         ++t;
+        if (!drawn) { s_a = sample_step(a, rng); r_a = a.step_rec[s_a]; }              // :990
+        drawn = false;
         RefTermND cur;
-        if (!ref_sample_nd<LDS_TABLES>(a, path_tab, zeta_tab, rng, cur)) continue;
+        if (!ref_sample_nd<LDS_TABLES>(a, path_tab, zeta_tab, rng, s_a, r_a, cur)) continue;
         const bool oa = (cur.ends & 1u) != 0u, ob = (cur.ends & 2u) != 0u;
         const uint64_t idx_i = (uint64_t)cur.ni * 2u + (oa ? 1u : 0u);                 // :1099-1103
         const uint64_t idx_j = (uint64_t)cur.nj * 2u + (ob ? 1u : 0u);
@@ -69,6 +74,7 @@ __device__ __forceinline__ void ref_run_nd(const KArgs &a, const uint4 *path_tab
         const double r = delta / mag;                                                  // :1142
         const bool same = idx_i == idx_j;   // reference stores c_i-r then c_j+r from values
                                             // loaded before either store: the 2nd wins (:1145-1148)
+        if (d + 1u < quota && t < max_att) { s_a = sample_step(a, rng); r_a = a.step_rec[s_a]; drawn = true; }   // the next trip's :990
 #pragma unroll
         for (int k = 0; k < D; ++k) {                                                  // :1143-1149
             const double r_d = r * deltas[k];
