@@ -116,6 +116,30 @@ def test_cli_layout_tsv(bins, tmp_path):
     assert abs(stress - O.layout_stress(oracle_graph(g), 2, lay.coords, 10000)) < 1e-5
 
 
+@pytest.mark.gpu
+def test_cli_reference_sampler_flag(bins, tmp_path):
+    """`--reference-sampler` (= --bundle 1) on a graph the auto policy would give to the team kernel: the engine line reports the
+    sampler that ran; both write a sorted GFA of the same nodes."""
+    g = G.synth_bubbles(20_000, 8, 4)
+    src = tmp_path / "b.gfa"
+    first = g.path_first_step.astype(int)
+    with open(src, "w") as fh:
+        fh.write("H\tVN:Z:1.0\n")
+        fh.write("".join(f"S\t{i}\t{'A' * l}\n" for i, l in zip(g.node_ids.tolist(), g.node_len.tolist())))
+        for pth, name in enumerate(g.path_names):
+            fh.write(f"P\t{name}\t" + ",".join(f"{i}+" for i in g.step_node_id[first[pth]:first[pth + 1]].tolist()) + "\t*\n")
+    seen = {}
+    for extra, want in (([], "(bundle 64)"), (["--reference-sampler"], "(bundle 1)")):
+        o = str(tmp_path / ("o%d.gfa" % len(extra)))
+        r = subprocess.run([bins[0], "-i", str(src), "-o", o, "-p", "Y", "--iter-max", "30", "-v", "1"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert want in r.stderr, r.stderr
+        seen[want] = G.load_gfa(o)
+    a, b = seen["(bundle 64)"], seen["(bundle 1)"]
+    assert a.n_nodes == b.n_nodes == g.n_nodes and a.n_steps == b.n_steps == g.n_steps
+
+
 # ---- the multi-device C ABI from C++: one host thread per rank, gfs_rank_run with a caller-supplied collective ---------
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [["2"], ["4", "60000", "24", "6000", "0", "2"], ["3", "40000", "12", "8000", "2", "1"],
