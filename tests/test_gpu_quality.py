@@ -240,7 +240,7 @@ def test_default_flags_on_drb1_tiled_in_series(shuffle_seed):
     # (b) the reference's default schedule: behind, by a bounded amount
     x_def, x_b1 = res[100]
     s_ref, s_def = O.stress_1d(og, x_b1, 2_000_000), O.stress_1d(og, x_def, 2_000_000)
-    assert s_def <= 1.15 * s_ref, (s_ref, s_def)               # measured +4...12 %
+    assert s_def <= 1.20 * s_ref, (s_ref, s_def)               # measured +4...12 % (the sampled stress itself: +-3 % per run)
     pr, pn = _profile(g, x_b1), _profile(g, x_def)
     ratio = pn / pr
     assert ratio[0] <= 2.0 and np.max(ratio[1:]) <= 1.30, np.round(ratio, 3).tolist()
