@@ -201,6 +201,16 @@ def layout_leg(g, device_index, args, dims=2):
     out = {"value": upd / dt, "unit": "term-updates/s", "dimensions": dims, "steps": launches,
            "sampling_bundle": int(s1.bundle), "run_trips": int(s1.run_trips), "avg_launch_ms": kms, "algorithmic_bytes_per_update": algo,
            "roofline_frac": (upd / launches) * algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # the same launch against the memory-side atomic units (requests per update from the committed PMC pass of this kernel)
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
+            tl = json.load(fh).get("layout_2d") or {}
+    except (OSError, ValueError):
+        tl = {}
+    if dims == 2 and tl.get("atomic_requests_per_update"):
+        req = float(tl["atomic_requests_per_update"])
+        out.update(atomic_requests_per_update=req, atomic_unit_frac=req * (upd / launches) / (kms * 1e-3) / ATOMIC_UNIT_PEAK,
+                   counter_bytes_per_update=tl.get("hbm_bytes_per_update"), counters_source=tl.get("source"))
     # quality of the default layout kernel against reference streams, 525k-node bubble graph
     gb = G.synth_bubbles(400_000, 24, 6)
     pb = P.LayoutSGDParams.from_graph(gb, dims, 1)

@@ -133,7 +133,20 @@ def main():
         if atom:
             out["atomic_requests_per_update"] = atom[0] / args.updates
         root = os.path.dirname(os.path.dirname(os.path.abspath(args.dst_prefix)))
-        with open(os.path.join(root, "traffic_latest.json"), "w") as fh:
+        tpath = os.path.join(root, "traffic_latest.json")
+        try:
+            with open(tpath) as fh:
+                prev = json.load(fh)
+        except (OSError, ValueError):
+            prev = {}
+        if "sgdnd" in k:
+            # a profile of the layout launches: kept beside the headline kernel's figures, which stay as they are
+            out["algorithmic_bytes_per_update"] = 104
+            prev["layout_2d"] = out
+            out = prev
+        elif "layout_2d" in prev:
+            out["layout_2d"] = prev["layout_2d"]
+        with open(tpath, "w") as fh:
             json.dump(out, fh, indent=1)
         print(json.dumps(out, indent=1))
 
