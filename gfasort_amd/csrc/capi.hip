@@ -31,6 +31,7 @@ hipError_t warm_module_1d();
 hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu);
 hipError_t warm_module_nd();
 hipError_t warm_module_nd_team();
+int nd_team_waves();
 hipError_t warm_module_index();
 hipError_t init_positions_device(const uint32_t *d_node_len, const uint32_t *d_perm, double *d_x, uint64_t n);
 hipError_t reorder_positions_device(const double *d_src, double *d_dst, const uint32_t *d_perm, uint64_t N, uint32_t D,
@@ -413,10 +414,10 @@ static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
     // Round 2: the 1D team kernels run 4 waves per SIMD (128 VGPRs; twin trips keep three blocks of a trip in flight) = 1024
     // lanes per CU; 5 waves (96 VGPRs) spill 58 registers and are slower (profiles/r02/two_partners.log).  The fused launch
     // further bounds the count by the workgroups that are resident at once (setup_common).
-    // The layout team kernels live on registers (a twin trip holds six records and three ends' coordinates): built for 2 waves
-    // per SIMD (203 VGPRs, nothing spilled) = 512 lanes per CU they run C4 at 36.6 G updates/s, for 3 waves (28 spilled) at
-    // 29.6-34.9, for 4 (244 spilled) at 18 (profiles/r02/layout_twin.log).
-    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1024 : (team && c->dims >= 2) ? 512 : 976);
+    // The layout team kernels live on registers (a twin trip holds six records and three ends' coordinates): built for 3 waves
+    // per SIMD (165 VGPRs at D = 2, nothing spilled) = 768 lanes per CU (sgd_kernels_nd_team.hip nd_team_waves; round 2's
+    // kernel needed 203 and ran two).
+    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1024 : (team && c->dims >= 2) ? 256u * (unsigned)gfs::nd_team_waves() : 976);
     // keep >= 8 updates per stream per batch on small graphs
     const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
     // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight
@@ -692,7 +693,10 @@ int gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32
     };
     hipError_t e;
 #define GFS_TRY(what, expr) if ((e = (expr)) != hipSuccess) { free_tmp(); return bail(what, e); }
-    GFS_TRY("hipMalloc step_rec", hipMalloc(&c->d_step_rec, std::max<uint64_t>(S, 1) * sizeof(uint4)));
+    // (one record of padding, zeroed: the layout team kernels read the record AFTER a step for its node's length and use it
+    // only where that step is not its path's last — so the graph's very last step needs no clamp, sgd_kernels_nd_team.hip)
+    GFS_TRY("hipMalloc step_rec", hipMalloc(&c->d_step_rec, (S + 1) * sizeof(uint4)));
+    GFS_TRY("hipMemset step_rec", hipMemset(c->d_step_rec + S, 0, sizeof(uint4)));
     GFS_TRY("hipMalloc path_rec", hipMalloc(&c->d_path_rec, prec.size() * sizeof(uint4)));
     GFS_TRY("hipMalloc path_len", hipMalloc(&c->d_path_len, std::max<uint64_t>(P, 1) * 8));
     GFS_TRY("hipMalloc perm", hipMalloc(&c->d_perm, std::max<uint64_t>(N, 1) * 4));
@@ -772,7 +776,7 @@ int gfs_ctx_upload_positions(gfs_ctx *c, const double *host, uint64_t n) {
     if (!c->d_x) return fail(GFS_E_STATE, "context not set up");
     if (n != c->x_len) return fail(GFS_E_ARG, "positions length mismatch");
     HIPCHK(hipSetDevice(c->device));
-    // device order: 1D x[slot]; nD two end planes coords[end][slot][dim] — reordered on the device
+    // device order: 1D x[slot]; nD the planes coords[end][dim][slot] — reordered on the device
     double *d_stage = nullptr;
     HIPCHK(hipMalloc(&d_stage, n * 8));
     hipError_t e = hipMemcpy(d_stage, host, n * 8, hipMemcpyHostToDevice);

@@ -265,16 +265,14 @@ hipError_t first_visit_layout_device(const uint32_t *d_step_node, uint64_t n_ste
 }
 
 // ---- ABI order <-> device order of positions / coordinates ------------------------------------------------
-// ABI: x[k] (1D, D = 0) or coords[(k*2 + end)*D + dim] by dense index k; device: x[perm[k]] or the end planes
-// coords[(end*N + perm[k])*D + dim] (sgd_device.h coord_ptr).  to_device = 1: abi -> dev, else dev -> abi.
+// ABI: x[k] (1D, D = 0) or coords[(k*2 + end)*D + dim] by dense index k; device: x[perm[k]] or the end x dimension planes
+// coords[(end*D + dim)*N + perm[k]] (sgd_device.h coord_ptr).  to_device = 1: abi -> dev, else dev -> abi.
 __global__ void reorder_positions_kernel(const double *src, double *dst, const uint32_t *perm, uint64_t N, uint32_t D, int to_device) {
     const uint64_t W = D ? 2ull * D : 1ull, total = N * W;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const uint64_t k = t / W, r = t - k * W;                  // t walks the ABI order
-        uint64_t dev;
-        if (D == 0) dev = perm[k];
-        else { const uint64_t end = r / D, d = r - end * D; dev = (end * N + perm[k]) * D + d; }
+        const uint64_t k = t / W, r = t - k * W;                  // t walks the ABI order; r = end*D + dim
+        const uint64_t dev = r * N + perm[k];
         if (to_device) dst[dev] = src[t]; else dst[t] = src[dev];
     }
 }

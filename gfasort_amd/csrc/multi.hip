@@ -408,20 +408,20 @@ int gfs_rank_create(const gfs_graph_view *g, const gfs_sgd_params *p, uint64_t d
     if (rc == GFS_NOTHING_TO_DO) r->idle = true;
     r->x_len = gfs_ctx_positions_len(r->ctx);
 
-    // exchange tables (element space: 1D x[slot]; nD two end planes coords[end][slot][dim])
+    // exchange tables (element space: 1D x[slot]; nD the end x dimension planes coords[end][dim][slot], sgd_device.h coord_ptr)
     if (multi && r->x_len) {
-        const uint64_t D = dims ? dims : 1, planes = dims ? 2 : 1, N = g->n_nodes;
+        const uint64_t planes = dims ? 2ull * dims : 1ull, N = g->n_nodes;
         uint64_t off = 0;
         for (uint64_t pl = 0; pl < planes; ++pl)
             for (uint32_t k = 0; k < n_seg; ++k) {
-                r->esegs.push_back({ (pl * N + seg_lo[k]) * D, (pl * N + seg_hi[k]) * D, off });
-                off += (seg_hi[k] - seg_lo[k]) * D;
+                r->esegs.push_back({ pl * N + seg_lo[k], pl * N + seg_hi[k], off });
+                off += seg_hi[k] - seg_lo[k];
             }
         r->total = off;
         for (uint32_t k = 0; k < n_seg; ++k) r->shared_slots += seg_hi[k] - seg_lo[k];
         for (uint64_t pl = 0; pl < planes; ++pl)
             for (uint32_t k = 0; k < n_own; ++k)
-                if (own_rank[k] == cfg->rank) r->owned.push_back({ (pl * N + own_lo[k]) * D, (pl * N + own_hi[k]) * D, 0 });
+                if (own_rank[k] == cfg->rank) r->owned.push_back({ pl * N + own_lo[k], pl * N + own_hi[k], 0 });
         if (hipSetDevice(cfg->device) != hipSuccess) return bail(gfs_set_error(GFS_E_HIP, "hipSetDevice failed"));
         auto up = [&](const std::vector<gfs::ESeg> &v, gfs::ESeg **d) -> int {
             if (v.empty()) return GFS_OK;

@@ -90,7 +90,7 @@ struct KArgs {
     const uint4    *path_rec;
     const uint64_t *path_len;      // bp length per path (nD: length of a path's last node)
     const double   *zetas;
-    double         *x;             // 1D: x[slot]; nD: END PLANES coords[end][slot][D] (see coord_ptr)
+    double         *x;             // 1D: x[slot]; nD: planes coords[end][dim][slot] (see coord_ptr)
     uint64_t       *rng;           // [4][n_streams] SoA
     unsigned long long *counters;  // [slots][8]: [s][0] successful updates, [s][1] attempts (sgd_kernel_common.h)
     void           *trace;         // gfs_term[n_streams*trace_per_stream] or null
@@ -151,14 +151,18 @@ __device__ __forceinline__ int crowd_shift(const KArgs &a, const uint4 &ra, cons
 }
 __device__ __forceinline__ double crowd_scale(double mu, int k) { return k ? ldexp(mu, -k) : mu; }
 
-// nD coordinates on the device: two END PLANES, coords[end][slot][dim].  (The ABI and Layout.coords,
-// layout.rs:14, are [node][end][dim]; upload/download translate.)  A run of consecutive nodes taking the
-// same end is then 8*D*B contiguous bytes: every 64-B line it touches is fully used, and the atomics of a
-// run need half the requests of the interleaved order, where each line also holds the other end.
+// nD coordinates on the device: END x DIMENSION PLANES, coords[end][dim][slot].  (The ABI and Layout.coords, layout.rs:14,
+// are [node][end][dim]; upload/download translate.)  A run of consecutive nodes taking the same end then reads and adds
+// 8*B CONTIGUOUS bytes per dimension, lane l the l-th of them: every instruction of a team wave is 8 fully used lines, and
+// nothing has to be re-dealt between lanes first.  (Round 2 kept [end][slot][dim]: the same request count, but only after
+// 12-24 lane permutes per trip, ~12 % of the layout kernel's time — profiles/r03/nd_ablate.log.)  A lone term of a reference
+// stream issues one request per end and dimension in either order.
+// coord_ptr: dimension 0 of an end; coord_step: elements between its dimensions.
 template <int D>
 __device__ __forceinline__ double *coord_ptr(const KArgs &a, uint32_t slot, bool end) {
-    return a.x + ((end ? (uint64_t)a.n_nodes : 0ull) + slot) * D;
+    return a.x + (end ? (uint64_t)a.n_nodes * D : 0ull) + slot;
 }
+__device__ __forceinline__ uint64_t coord_step(const KArgs &a) { return (uint64_t)a.n_nodes; }
 
 // zeta index rule (sgd.rs:463-469)
 __device__ __forceinline__ uint32_t space_index(const KArgs &a, uint32_t jump) {

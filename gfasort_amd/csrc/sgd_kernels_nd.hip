@@ -4,7 +4,7 @@
 namespace gfs {
 
 // ------------------------------------------------------------------------------------------
-// K2: nD, D compile-time.  coords in end planes [end][slot][dim] (sgd_device.h coord_ptr); the trace
+// K2: nD, D compile-time.  coords in planes [end][dim][slot] (sgd_device.h coord_ptr); the trace
 // speaks the reference's index 2*node+end (sgd.rs:1099-1103).
 // Node lengths come from the step records themselves: pos[s+1]-pos[s] inside a path,
 // path_len - pos[s] for a path's last step (identical to graph.nodes[id].sequence.len(),
@@ -60,12 +60,13 @@ __device__ __forceinline__ void ref_run_nd(const KArgs &a, const uint4 *path_tab
         const uint64_t idx_i = (uint64_t)cur.ni * 2u + (oa ? 1u : 0u);                 // :1099-1103
         const uint64_t idx_j = (uint64_t)cur.nj * 2u + (ob ? 1u : 0u);
         double *ci = coord_ptr<D>(a, cur.ni, oa), *cj = coord_ptr<D>(a, cur.nj, ob);
+        const uint64_t cs = coord_step(a);
         const double mu = crowd_scale(fmin(a.it.eta * (1.0 / cur.term_dist), 1.0), cur.crowd);   // :1085-1086
         double deltas[D];
         double mag_sq = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {                                                  // :1108-1113
-            deltas[k] = load_pos<ATOMIC_LOADS>(ci + k) - load_pos<ATOMIC_LOADS>(cj + k);
+            deltas[k] = load_pos<ATOMIC_LOADS>(ci + k * cs) - load_pos<ATOMIC_LOADS>(cj + k * cs);
             mag_sq += deltas[k] * deltas[k];
         }
         if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }                       // :1116-1119
@@ -78,8 +79,8 @@ __device__ __forceinline__ void ref_run_nd(const KArgs &a, const uint4 *path_tab
 #pragma unroll
         for (int k = 0; k < D; ++k) {                                                  // :1143-1149
             const double r_d = r * deltas[k];
-            if (!same) add_pos(ci + k, -r_d);
-            add_pos(cj + k, r_d);
+            if (!same) add_pos(ci + k * cs, -r_d);
+            add_pos(cj + k * cs, r_d);
         }
         ++d;                                                                           // :1151
         if (TRACE) {

@@ -12,21 +12,22 @@ hipError_t launch_nd_ref(int dims, const KArgs &a, bool lds_tables, bool atomic_
 // flips of a term (sgd.rs:1062,1071) are drawn ONCE PER RUN, by the leader's stream right after it
 // sampled the leader term: every lane of the run uses the same pair.  Each term's flips are still two
 // fair independent bits; what changes is, again, only the correlation between the concurrent terms of
-// a run.  With the coordinates in end planes (coord_ptr) a run on one strand then reads and updates
-// 8*D*B CONTIGUOUS bytes per side: half the atomic requests and half the coordinate lines of
-// per-lane flips (measured: 1.08 -> 0.55 requests per update for D = 2, the atomic unit being what
-// binds this kernel).  Node lengths come from the following step record as in K2.  Atomics are
+// a run.  With the coordinates in end x dimension planes (coord_ptr) a run on one strand then reads and
+// updates 8*B CONTIGUOUS bytes per side and dimension: half the atomic requests and half the coordinate
+// lines of per-lane flips (measured: 1.08 -> 0.55 requests per update for D = 2, the atomic unit being
+// what binds this kernel).  Node lengths come from the following step record as in K2.  Atomics are
 // issued in the trip that computes them (no deferral).
 // ------------------------------------------------------------------------------------------
 // One trip = (slot t of the pass, trip seg of its run, colour) — as in K1b (sgd_kernels_1d.hip): long runs for B = 64
 // (sgd_device.h run_trips) and two colours for jumps shorter than the run (two_colour).
 struct TripND {
-    uint64_t sa = 0, sb = 0, first = 0;
+    uint64_t first = 0;                                   // the path's first step (wave-uniform at B = 64)
+    uint32_t qa = 0, qb = 0, qc = 0;                      // this lane's steps a, b (and c, twin trip) as ranks in the path
     uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0), na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
     uint4 rc = make_uint4(0, 0, 0, 0), nc = make_uint4(0, 0, 0, 0);    // twin trip: the second partner's step and the step after it
-    // (na, nb, nc: the steps after them, for the node lengths, sgd.rs:1051-1058.  Whole records: loading only their position
+    // (na, nb, nc: the steps after them, for the node lengths, sgd.rs:1051-1058 — unused where the step is its path's last, so the
+    // graph's last step reads the zeroed record the index keeps behind the table, capi.hip.  Whole records: loading only their position
     // words — 8 of the 16 bytes, 10 registers less — made the kernel slower, 32.9 G updates/s on C4.)
-    uint64_t sc = 0;
     uint32_t cnt = 0, flips = 0, k = 1, off = 0;
     bool valid = false, two = false, fused = false;   // fused: both colours of a short-jump trip in this one (fused_trip_nd)
     bool twin = false;                                // both partners of an aligned leader in this trip (twin_trip_nd)
@@ -35,6 +36,11 @@ struct TripND {
 
 // lflips: the run's end flips — bit 0: step a, bit 1: partner 0's step b, bit 2: partner 1's (two partners per leader,
 // sgd_device.h Leader: D >= 2 at B = 64).  tr.flips = bit 0: a, bit 1: the b of the partner this trip works on, bit 2: as drawn.
+// (wave-uniform by construction at B = 64 — every input is a leader value read from ONE lane — but not always for the compiler:
+// said explicitly, the trip machine's control flow is scalar branches and its arithmetic scalar instructions)
+template <int B> __device__ __forceinline__ uint32_t uni(uint32_t v) { return B == 64 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v; }
+template <int B> __device__ __forceinline__ bool uni(bool v) { return B == 64 ? __builtin_amdgcn_readfirstlane((int)v) != 0 : v; }
+
 template <int B, bool FUSE>
 __device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, uint32_t lflips, int t, uint32_t seg, uint32_t p, uint32_t colour,
                                                int sub, int q, TripND &tr) {
@@ -45,16 +51,16 @@ __device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, 
     const uint32_t ra0 = p ? bcast<B>(L.ra1, ll) : bcast<B>(L.ra0, ll), rb0 = p ? bcast<B>(L.rb1, ll) : bcast<B>(L.rb0, ll);
     const uint32_t fl = bcast<B>(lflips, ll);
     tr.first = bcast_first<B>(L, ll); tr.cnt = bcast<B>(L.cnt, ll);
+    const uint4 *recs = a.step_rec + tr.first;                     // the path's records
     tr.flips = (fl & 1u) | (((fl >> (1u + p)) & 1u) << 1) | (fl & 4u);
     // (the number of trips must not depend on the partner: the trips of a slot go seg by seg, both partners each)
-    tr.k = (B == 64 && ((okw | (okw >> 8)) & 1u) && tr.cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, tr.cnt) : 1u;
-    tr.off = B == 64 ? run_offset((uint32_t)B, tr.cnt, tr.k, ra0, rb0, seg) : 0u;
-    tr.valid = expand_run<B>(ok, tr.first, tr.cnt, ra0, rb0, sub, colour, tr.off, tr.sa, tr.sb);
-    tr.mshift = merged_trip_shift<B>(ok, tr.cnt, ra0, rb0, tr.off);
-    const bool two = !(a.dbg & 0x08u) && two_colour<B>(ok, tr.cnt, ra0, rb0);
+    tr.k = uni<B>((B == 64 && ((okw | (okw >> 8)) & 1u) && tr.cnt >= 2u * B) ? run_trips(a.chain, (uint32_t)B, tr.cnt) : 1u);
+    tr.off = uni<B>(B == 64 ? run_offset((uint32_t)B, tr.cnt, tr.k, ra0, rb0, seg) : 0u);
+    tr.mshift = (int)uni<B>((uint32_t)merged_trip_shift<B>(ok, tr.cnt, ra0, rb0, tr.off));
+    const bool two = uni<B>(!(a.dbg & 0x08u) && two_colour<B>(ok, tr.cnt, ra0, rb0));
     tr.two = B == 64 ? two : (__any(two) != 0);
     tr.ra = make_uint4(0, 0, 0, 0); tr.rb = tr.ra; tr.na = tr.ra; tr.nb = tr.ra; tr.rc = tr.ra; tr.nc = tr.ra;
-    tr.fused = FUSE && B == 64 && tr.mshift != 0 && colour == 0 && two && !(a.dbg & 0x100u);
+    tr.fused = uni<B>(FUSE && B == 64 && tr.mshift != 0 && colour == 0 && two && !(a.dbg & 0x100u));
     // both partners line-aligned long jumps whose blocks keep two trips apart: their a-runs are the same blocks, one trip serves both
     // (sgd_kernels_1d.hip expand_trip has the reasons)
     tr.twin = FUSE && B == 64 && p == 0u && a.partners == 2u && (okw & 3u) == 3u && ((okw >> 8) & 3u) == 3u && !(a.dbg & 0x04u);
@@ -62,73 +68,58 @@ __device__ __forceinline__ void expand_trip_nd(const KArgs &a, const Leader &L, 
         const uint32_t rb1 = bcast<B>(L.rb1, ll);
         const int64_t gap = (int64_t)rb0 - (int64_t)rb1, lim = 192;
         if (gap < lim && gap > -lim) tr.twin = false;
-        else {
-            tr.sa = tr.first + ra0 + tr.off + (uint32_t)sub;
-            tr.sb = tr.first + rb0 + tr.off + (((uint32_t)sub + ((okw >> 2) & 7u)) & 63u);
-            tr.sc = tr.first + rb1 + tr.off + (((uint32_t)sub + ((okw >> 10) & 7u)) & 63u);
+    }
+    tr.twin = uni<B>(tr.twin);
+    if (tr.twin) {
+        {
+            const uint32_t rb1 = bcast<B>(L.rb1, ll);
+            tr.qa = ra0 + tr.off + (uint32_t)sub;
+            tr.qb = rb0 + tr.off + (((uint32_t)sub + ((okw >> 2) & 7u)) & 63u);
+            tr.qc = rb1 + tr.off + (((uint32_t)sub + ((okw >> 10) & 7u)) & 63u);
             tr.valid = true;
-            tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb]; tr.rc = a.step_rec[tr.sc];
-            tr.na = a.step_rec[tr.sa + 1u < a.n_steps ? tr.sa + 1u : tr.sa];
-            tr.nb = a.step_rec[tr.sb + 1u < a.n_steps ? tr.sb + 1u : tr.sb];
-            tr.nc = a.step_rec[tr.sc + 1u < a.n_steps ? tr.sc + 1u : tr.sc];
+            tr.ra = recs[tr.qa]; tr.rb = recs[tr.qb]; tr.rc = recs[tr.qc];
+            tr.na = recs[(uint64_t)tr.qa + 1u];
+            tr.nb = recs[(uint64_t)tr.qb + 1u];
+            tr.nc = recs[(uint64_t)tr.qc + 1u];
             return;
         }
     }
     if (tr.fused) {
         // every lane takes its own step of the trip, its partner's record and the two records after them (node lengths)
         const int dst = sub + tr.mshift;
-        tr.sa = tr.first + merged_trip_base(tr.cnt, ra0, tr.off) + (uint32_t)sub;
-        tr.sb = (uint64_t)((int64_t)tr.sa + tr.mshift);
+        tr.qa = merged_trip_base(tr.cnt, ra0, tr.off) + (uint32_t)sub;
+        tr.qb = (uint32_t)((int64_t)tr.qa + tr.mshift);                // inside the path (merged_trip_shift)
         tr.valid = dst < 0 || dst > 63;                                // partner beyond the trip's 64 steps
-        tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb];
-        tr.na = a.step_rec[tr.sa + 1u < a.n_steps ? tr.sa + 1u : tr.sa];
-        tr.nb = a.step_rec[tr.sb + 1u < a.n_steps ? tr.sb + 1u : tr.sb];
+        tr.ra = recs[tr.qa]; tr.rb = recs[tr.qb];
+        tr.na = recs[(uint64_t)tr.qa + 1u];
+        tr.nb = recs[(uint64_t)tr.qb + 1u];
         return;
     }
+    // the generic trip: this lane's own term of the run, if it has one
+    uint64_t sa = 0, sb = 0;
+    tr.valid = expand_run<B>(ok, tr.first, tr.cnt, ra0, rb0, sub, colour, tr.off, sa, sb);
     if (tr.valid) {
-        tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb];
-        tr.na = a.step_rec[tr.sa + 1u < a.n_steps ? tr.sa + 1u : tr.sa];
-        tr.nb = a.step_rec[tr.sb + 1u < a.n_steps ? tr.sb + 1u : tr.sb];
+        tr.qa = (uint32_t)(sa - tr.first); tr.qb = (uint32_t)(sb - tr.first);
+        tr.ra = a.step_rec[sa]; tr.rb = a.step_rec[sb];
+        tr.na = a.step_rec[sa + 1u];
+        tr.nb = a.step_rec[sb + 1u];
     }
 }
 
-// The adds of one trip, D >= 2.  The D coordinates of an end are adjacent (8*D bytes) and so are the same ends of
-// neighbouring nodes.  Each lane brings up to two adds (A, B: pointer to an end's coordinates, D values, flag); they are
-// re-dealt so that a group of P = 2 (D=2) or 4 (D=3) adjacent lanes of one instruction carries the D coordinates of the
-// SAME end: one instruction then covers 64/P neighbouring nodes = 512 (384 for D=3) contiguous bytes = 8-9 (6-7)
-// requests.  Wave-uniform control flow: all lanes take part in the shuffles.
-// (The flag of an add travels in bit 0 of its 8-byte aligned pointer, and a call that has no second add — HAS_B false —
-// shuffles nothing for it: 6 or 12 lane permutes per pass where round 2 spent 14.  Measured neutral on C4 — the kernel's time is
-// not in these shuffles, profiles/r03/nd_ablate.log — kept because it is less work.)
-__device__ __forceinline__ uint64_t shfl_u64(const uint64_t v, const int src) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
+// The adds of one trip, D >= 2: each lane brings up to two (A, B: pointer to dimension 0 of an end, D values, flag).  In the
+// dimension planes (sgd_device.h coord_ptr) the lanes of a run address consecutive doubles, so an instruction of the wave is
+// 8 full lines as it stands.  (Round 2 kept [end][slot][dim] and re-dealt the adds between lanes first: 12-24 lane permutes
+// per trip, ~12 % of the kernel, profiles/r03/nd_ablate.log.)
 template <int D, bool HAS_B = true>
-__device__ __forceinline__ void issue_adds_regrouped(const int lane, const double (&vA)[D], const double (&vB)[D],
-                                                     const unsigned long long pA, const unsigned long long pB, const int fA, const int fB,
-                                                     const bool dry = false) {
-    constexpr int P = D <= 2 ? 2 : 4;
-    const int d = lane & (P - 1);
-    const unsigned long long tA = pA | (fA ? 1ull : 0ull), tB = pB | (fB ? 1ull : 0ull);
+__device__ __forceinline__ void issue_adds(const uint64_t cs, const double (&vA)[D], const double (&vB)[D],
+                                           double *pA, double *pB, const bool fA, const bool fB) {
+    if (fA) {
 #pragma unroll
-    for (int pass = 0; pass < P; ++pass) {
-        const int m = pass * (64 / P) + lane / P;
-        double va = 0.0, vb = 0.0;
+        for (int d = 0; d < D; ++d) add_pos(pA + d * cs, vA[d]);
+    }
+    if (HAS_B && fB) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const double ak = __shfl(vA[k], m, 64);
-            if (k == d) va = ak;
-            if (HAS_B) { const double bk = __shfl(vB[k], m, 64); if (k == d) vb = bk; }
-        }
-        const unsigned long long pa = shfl_u64(tA, m);
-        unsigned long long pb = 0ull;
-        if (HAS_B) pb = shfl_u64(tB, m);
-        if (dry) { asm volatile("" :: "v"(va), "v"(vb), "v"(pa), "v"(pb)); continue; }   // ablation: the shuffles without the adds
-        if (d < D) {
-            if (pa & 1ull) add_pos(reinterpret_cast<double *>(pa & ~7ull) + d, va);
-            if (HAS_B && (pb & 1ull)) add_pos(reinterpret_cast<double *>(pb & ~7ull) + d, vb);
-        }
+        for (int d = 0; d < D; ++d) add_pos(pB + d * cs, vB[d]);
     }
 }
 
@@ -136,28 +127,34 @@ __device__ __forceinline__ void issue_adds_regrouped(const int lane, const doubl
 // form of K1b's fused_trip (sgd_kernels_1d.hip).  A lane's step is the a-side of its own term in one colour and the
 // b-side of its neighbour's term in the other; the two roles take the end the run's flips select (sgd.rs:1062-1077), so
 // a lane keeps the coordinates of its a-end and of its b-end in registers (one set when both flips agree).  Partners
-// inside the trip are read from the lane that holds them; colour 1 computes on what colour 0 produced.  Same terms, same
-// arithmetic, same order as the two generic trips.  Returns false when the quota filled between the colours.
+// inside the trip are read from the lane that holds them; colour 1 computes on what colour 0 produced.  Same terms and same
+// arithmetic as the two generic trips; as in K1b's fused_trip a lane's OWN ends take ONE add each for both colours — the
+// sum of what the lane gave as an acting lane in one colour and took as a partner in the other (its registers hold
+// (c - r) + r', memory receives c + (-r + r')): one instruction per dimension when the run's two flips agree, two when
+// they differ, where the adds per colour were twice that — these trips are a quarter of the layout kernel's updates and
+// had 0.75 atomic requests per update against a twin trip's 0.375.  Partners beyond the trip are added per colour.
+// Returns false when the quota filled between the colours.
 template <int D, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ bool fused_trip_nd(const KArgs &a, const TripND &cur, const int lane, const uint32_t tid,
                                               const uint64_t wave_quota, uint64_t &wave_done, uint32_t &done, uint32_t &att, uint32_t &ntr) {
+    const uint64_t cs = coord_step(a);
     const int s = cur.mshift, z = s < 0 ? -s : s;
     const int dst = lane + s, src = lane - s;
     const bool out = cur.valid;
     const int dstc = out ? lane : dst, srcc = (src < 0 || src > 63) ? lane : src;
     const uint32_t grp = ((cur.off + (uint32_t)lane) / (uint32_t)z) & 1u;
     const bool fa = (cur.flips & 1u) != 0u, fb = (cur.flips & 2u) != 0u;      // wave-uniform
-    const uint64_t last_step = cur.first + cur.cnt - 1u;
-    const uint64_t plen = a.path_len[rec_path(cur.ra)];
+    const uint32_t last_q = cur.cnt - 1u;
+    const uint64_t plen = a.path_len[uni<64>(rec_path(cur.ra))];      // (every lane of the trip is on the leader's path)
     // my step in both roles
-    const uint64_t p_own = rec_pos_u64(cur.ra), e_own = cur.sa == last_step ? plen : rec_pos_u64(cur.na);
+    const uint64_t p_own = rec_pos_u64(cur.ra), e_own = cur.qa == last_q ? plen : rec_pos_u64(cur.na);
     const bool rev_own = (cur.ra.y >> 31) != 0;
     const double len_own = (double)(e_own - p_own);
     const double pos_a = (double)p_own + (fa ? len_own : 0.0);                // sgd.rs:1047,1062-1064
     const bool end_a = fa ? !rev_own : rev_own;
     const bool end_b_own = fb ? !rev_own : rev_own;
     // my partner's step as b-side (its record is loaded whether it sits inside the trip or not)
-    const uint64_t p_p = rec_pos_u64(cur.rb), e_p = cur.sb == last_step ? plen : rec_pos_u64(cur.nb);
+    const uint64_t p_p = rec_pos_u64(cur.rb), e_p = cur.qb == last_q ? plen : rec_pos_u64(cur.nb);
     const bool rev_p = (cur.rb.y >> 31) != 0;
     const double pos_b = (double)p_p + (fb ? (double)(e_p - p_p) : 0.0);      // :1048,1071-1073
     const bool end_b = fb ? !rev_p : rev_p;
@@ -176,16 +173,20 @@ __device__ __forceinline__ bool fused_trip_nd(const KArgs &a, const TripND &cur,
     for (int d = 0; d < D; ++d) { ca[d] = 0.0; cb[d] = 0.0; cp[d] = 0.0; }
     if (node != 0xFFFFFFFFu) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) ca[d] = load_pos<ATOMIC_LOADS>(ptr_a + d);
+        for (int d = 0; d < D; ++d) ca[d] = load_pos<ATOMIC_LOADS>(ptr_a + d * cs);
         if (fa != fb) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) cb[d] = load_pos<ATOMIC_LOADS>(ptr_bo + d);
+            for (int d = 0; d < D; ++d) cb[d] = load_pos<ATOMIC_LOADS>(ptr_bo + d * cs);
         }
     }
     if (out && pnode != 0xFFFFFFFFu) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) cp[d] = load_pos<ATOMIC_LOADS>(ptr_p + d);
+        for (int d = 0; d < D; ++d) cp[d] = load_pos<ATOMIC_LOADS>(ptr_p + d * cs);
     }
+    double acc_a[D], acc_b[D];                                        // what my a-end and my b-end have taken so far
+    bool t_a = false, t_b = false, second = true;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { acc_a[d] = 0.0; acc_b[d] = 0.0; }
 #pragma unroll
     for (uint32_t colour = 0; colour < 2u; ++colour) {
         ++att;
@@ -231,26 +232,30 @@ __device__ __forceinline__ bool fused_trip_nd(const KArgs &a, const TripND &cur,
         for (int d = 0; d < D; ++d) rv[d] = __shfl(r_d[d], srcc, 64);
         const int vsrc = __shfl((int)valid, srcc, 64);
         const bool recv = src >= 0 && src <= 63 && vsrc != 0;
-        // registers: a lane acts (its a-end moves by -r) or receives (its b-end moves by +r) in a colour, never both
+        // a lane acts (its a-end moves by -r) or receives (its b-end moves by +r) in a colour, never both; registers and the
+        // sums for the adds at the end of the trip
         if (valid && !same) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) ca[d] = ca[d] - r_d[d];                // :1143-1146
+            for (int d = 0; d < D; ++d) { ca[d] = ca[d] - r_d[d]; acc_a[d] = t_a ? acc_a[d] - r_d[d] : -r_d[d]; }   // :1143-1146
+            t_a = true;
         }
         if (recv) {
+            if (fa != fb) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) { if (fa != fb) cb[d] = cb[d] + rv[d]; else ca[d] = ca[d] + rv[d]; }   // :1147-1148
+                for (int d = 0; d < D; ++d) { cb[d] = cb[d] + rv[d]; acc_b[d] = t_b ? acc_b[d] + rv[d] : rv[d]; }   // :1147-1148
+                t_b = true;
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) { ca[d] = ca[d] + rv[d]; acc_a[d] = t_a ? acc_a[d] + rv[d] : rv[d]; }
+                t_a = true;
+            }
         }
-        // the adds: A = my own end (acting: -r to the a-end; receiving: +r to the b-end), B = my partner's end when it lies
-        // outside the trip
-        double vA[D], vB[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) { vA[d] = valid ? -r_d[d] : rv[d]; vB[d] = r_d[d]; }
-        const unsigned long long pA = (unsigned long long)(valid ? ptr_a : ptr_bo), pB = (unsigned long long)ptr_p;
-        const int fA = (valid && !same) || recv, fB = valid && out;
-        if (!(a.dbg & 1u)) issue_adds_regrouped<D>(lane, vA, vB, pA, pB, fA, fB);
-        if (colour == 0 && wave_done >= wave_quota) return false;
+        // my partner's end when it lies outside the trip
+        if (!(a.dbg & 1u)) issue_adds<D, false>(cs, r_d, r_d, ptr_p, ptr_p, valid && out, false);
+        if (colour == 0 && wave_done >= wave_quota) { second = false; break; }
     }
-    return true;
+    if (!(a.dbg & 1u)) issue_adds<D>(cs, acc_a, acc_b, ptr_a, ptr_bo, t_a, t_b);
+    return second;
 }
 
 // TWIN trip of the layout kernel (D = 2, 3; B = 64; two partners, both line-aligned long jumps whose blocks keep two trips apart) — the nD
@@ -262,11 +267,12 @@ __device__ __forceinline__ bool fused_trip_nd(const KArgs &a, const TripND &cur,
 template <int D, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, const int lane, const uint32_t tid,
                                              const uint64_t wave_quota, uint64_t &wave_done, uint32_t &done, uint32_t &att, uint32_t &ntr) {
+    const uint64_t cs = coord_step(a);
     const bool fa = (cur.flips & 1u) != 0u, fb = (cur.flips & 2u) != 0u, fc = (cur.flips & 4u) != 0u;     // wave-uniform
-    const uint64_t last_step = cur.first + cur.cnt - 1u;
-    const uint64_t plen = a.path_len[rec_path(cur.ra)];
+    const uint32_t last_q = cur.cnt - 1u;
+    const uint64_t plen = a.path_len[uni<64>(rec_path(cur.ra))];      // (every lane of the trip is on the leader's path)
     // step a
-    const uint64_t p_a = rec_pos_u64(cur.ra), e_a = cur.sa == last_step ? plen : rec_pos_u64(cur.na);
+    const uint64_t p_a = rec_pos_u64(cur.ra), e_a = cur.qa == last_q ? plen : rec_pos_u64(cur.na);
     const bool rev_a = (cur.ra.y >> 31) != 0;
     const double pos_a = (double)p_a + (fa ? (double)(e_a - p_a) : 0.0);              // sgd.rs:1047,1062-1064
     const bool end_a = fa ? !rev_a : rev_a;
@@ -279,16 +285,16 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
     const bool no_loads = (a.dbg & 2u) != 0u;                                          // ablation (wrong results): no coordinate loads
     if (node != 0xFFFFFFFFu) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) ca[d] = no_loads ? (double)(node + d) : load_pos<ATOMIC_LOADS>(ptr_a + d);
+        for (int d = 0; d < D; ++d) ca[d] = no_loads ? (double)(node + d) : load_pos<ATOMIC_LOADS>(ptr_a + d * cs);
     }
     // the two partners: position, end, coordinates (all loaded before any add of the trip)
     double pos_p[2], cp[2][D]; double *ptr_p[2]; uint64_t idx_p[2]; uint32_t node_p[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const uint4 &rp = p ? cur.rc : cur.rb; const uint4 &np = p ? cur.nc : cur.nb;
-        const uint64_t sp = p ? cur.sc : cur.sb;
+        const uint32_t qp = p ? cur.qc : cur.qb;
         const bool fp = p ? fc : fb;
-        const uint64_t p_p = rec_pos_u64(rp), e_p = sp == last_step ? plen : rec_pos_u64(np);
+        const uint64_t p_p = rec_pos_u64(rp), e_p = qp == last_q ? plen : rec_pos_u64(np);
         const bool rev_p = (rp.y >> 31) != 0;
         pos_p[p] = (double)p_p + (fp ? (double)(e_p - p_p) : 0.0);                    // :1048,1071-1073
         const bool end_p = fp ? !rev_p : rev_p;
@@ -299,7 +305,7 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
         for (int d = 0; d < D; ++d) cp[p][d] = 0.0;
         if (rp.x != 0xFFFFFFFFu) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) cp[p][d] = no_loads ? (double)(rp.x + 7u * d) : load_pos<ATOMIC_LOADS>(ptr_p[p] + d);
+            for (int d = 0; d < D; ++d) cp[p][d] = no_loads ? (double)(rp.x + 7u * d) : load_pos<ATOMIC_LOADS>(ptr_p[p] + d * cs);
         }
     }
     bool touched = false, second = true;
@@ -346,22 +352,24 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
         if (p == 0 && wave_done >= wave_quota) second = false;
     }
     if (!(a.dbg & 1u)) {
-        // the adds, re-dealt (issue_adds_regrouped): a's end and b's end, then c's end
-        const bool dry = (a.dbg2 & 1u) != 0u;
-        issue_adds_regrouped<D>(lane, acc, rr[0], (unsigned long long)ptr_a, (unsigned long long)ptr_p[0], (int)touched, fadd[0], dry);
-        double none[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) none[d] = 0.0;
-        issue_adds_regrouped<D, false>(lane, rr[1], none, (unsigned long long)ptr_p[1], 0ull, fadd[1], 0, dry);
+        // the adds: a's end and b's end, then c's end
+        issue_adds<D>(cs, acc, rr[0], ptr_a, ptr_p[0], touched, fadd[0] != 0);
+        issue_adds<D, false>(cs, rr[1], rr[1], ptr_p[1], ptr_p[1], fadd[1] != 0, false);
     }
     return second;
 }
 
-// (2 waves per SIMD: the kernel needs ~200 VGPRs — a twin trip holds the records of three steps and of the steps after them, the
-// next trip's too, and three ends' coordinates; squeezed into 128 it spilled 244 of them and ran at half the rate.  Hence also
-// the bound on the workgroup size, checked by the host.)
+// (3 waves per SIMD, <= 168 VGPRs: 165 at D = 2, nothing spilled; D = 3 spills four cold ones.  Round 2's kernel needed ~210 and ran
+// two waves — a twin trip holds the records of three steps and of the steps after them, the next trip's too, and three ends'
+// coordinates.  What brought it under 168: the trip machine's state in scalar registers (uni), steps as 32-bit ranks in their
+// path, no lane permutes for the adds (dimension planes), the sampler's constants re-read per pass.  Three waves hide the
+// round trip of a trip's loads and adds behind two other waves' arithmetic: without the adds the kernel runs at 64 G updates/s
+// where two waves gave 51 (profiles/r03/nd_waves3.log).  Hence also the bound on the workgroup size, checked by the host.)
+#ifndef GFS_ND_TEAM_WAVES
+#define GFS_ND_TEAM_WAVES 3
+#endif
 template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) sgdnd_team_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND_TEAM_WAVES, GFS_ND_TEAM_WAVES))) sgdnd_team_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
     stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
@@ -372,9 +380,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int sub = lane & (B - 1);
     const int q = lane / B;
     const uint64_t T = a.n_streams;
+    const uint64_t cs = coord_step(a);
     Rng rng;
     rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid];
-    const uint32_t wave_first = tid & ~63u;
+    // (readfirstlane: the wave's quota, and with it every loop variable of the trip machine, is then wave-uniform for the
+    // compiler too — scalar registers and scalar arithmetic instead of 64 copies, as in K1c)
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
     uint64_t wave_quota = (uint64_t)a.quota_base * 64u;
     if (wave_first < a.quota_rem) wave_quota += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
     const uint64_t max_passes = (uint64_t)a.attempt_factor * (wave_quota / (64u * B) + 1u) + 16u;
@@ -384,30 +395,46 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     while (wave_done < wave_quota && passes < max_passes) {
         ++passes;
-        const Leader L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, rng);
+        // (the sampler reads its launch constants from the kernel-argument segment afresh in every pass — scalar loads, once per
+        // ~1000 trips — so that they do not sit in scalar registers through the trips: with them the trip machine spilled 74.)
+        KArgs as;
+        {
+            auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            typedef const __attribute__((address_space(4))) uint32_t kword;
+            kword *kw = (kword *)kp;
+            uint32_t *dw = reinterpret_cast<uint32_t *>(&as);
+            static_assert(sizeof(KArgs) % 4 == 0, "KArgs is copied by words");
+#pragma unroll
+            for (unsigned i = 0; i < sizeof(KArgs) / 4; ++i) dw[i] = kw[i];
+        }
+        const Leader L = sample_leader<LDS_TABLES>(as, path_tab, zeta_tab, rng);
         uint32_t lflips = rng.flip() | (rng.flip() << 1);                  // the run's end flips: bit 0 = a, bit 1 = b
         if (a.partners == 2u) lflips |= rng.flip() << 2;                   // bit 2 = the second partner's b
         int t = 0; uint32_t seg = 0, colour = 0, p = 0;
         TripND cur;
         expand_trip_nd<B, (D >= 2)>(a, L, lflips, t, seg, p, colour, sub, q, cur);
         for (;;) {
+            t = (int)uni<B>((uint32_t)t); seg = uni<B>(seg); colour = uni<B>(colour); p = uni<B>(p);
+            const bool c_two = uni<B>(cur.two), c_fused = uni<B>(cur.fused), c_twin = uni<B>(cur.twin);
+            const uint32_t c_k = uni<B>(cur.k);
             // the trip after this one (second colour, the leader's second partner, next trip of the run, next slot — as in
             // K1b, sgd_kernels_1d.hip): request its records now
             int t_n = t; uint32_t colour_n = 0u, seg_n = seg, p_n = p;
-            if (colour == 0 && cur.two && !cur.fused) colour_n = 1u;
-            else if (p == 0u && a.partners == 2u && !cur.twin) p_n = 1u;
-            else if (seg + 1u < cur.k) { seg_n = seg + 1u; p_n = 0u; }
+            if (colour == 0 && c_two && !c_fused) colour_n = 1u;
+            else if (p == 0u && a.partners == 2u && !c_twin) p_n = 1u;
+            else if (seg + 1u < c_k) { seg_n = seg + 1u; p_n = 0u; }
             else { t_n = t + 1; seg_n = 0u; p_n = 0u; }
             const bool have_n = t_n < B;
             TripND nxt;
             if (have_n) expand_trip_nd<B, (D >= 2)>(a, L, lflips, t_n, seg_n, p_n, colour_n, sub, q, nxt);
-            if (D >= 2 && B == 64 && cur.twin) {
+            if (D >= 2 && B == 64 && c_twin) {
                 if (!twin_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, done, att, ntr)) break;
                 if (wave_done >= wave_quota || !have_n) break;
                 cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
                 continue;
             }
-            if (D >= 2 && B == 64 && cur.fused) {
+            if (D >= 2 && B == 64 && c_fused) {
                 // (a quota that fills between the colours ends the iteration: the pass is dropped in nD, and with it the
                 // second colour — as the generic form drops whatever is left of a pass)
                 if (!fused_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, done, att, ntr)) break;
@@ -417,7 +444,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             bool valid = cur.valid;
             const uint4 ra = cur.ra, rb = cur.rb, na = cur.na, nb = cur.nb;
-            const uint64_t sa = cur.sa, sb = cur.sb, first = cur.first;
+            const uint32_t qa = cur.qa, qb = cur.qb;
             const uint32_t cnt = cur.cnt, flips = cur.flips;
             const int mshift = cur.mshift;
             ++att;
@@ -425,11 +452,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             uint64_t idx_i = 0, idx_j = 0;
             bool oa = false, ob = false;
             if (valid) {
-                const uint64_t last_step = first + cnt - 1u;
+                const uint32_t last_q = cnt - 1u;
                 const uint64_t plen = a.path_len[rec_path(ra)];
                 const uint64_t pa = rec_pos_u64(ra), pb = rec_pos_u64(rb);
-                const uint64_t ea = sa == last_step ? plen : rec_pos_u64(na);
-                const uint64_t eb = sb == last_step ? plen : rec_pos_u64(nb);
+                const uint64_t ea = qa == last_q ? plen : rec_pos_u64(na);
+                const uint64_t eb = qb == last_q ? plen : rec_pos_u64(nb);
                 double pos_a = (double)pa, pos_b = (double)pb;                         // sgd.rs:1047-1048
                 const double len_i = (double)(ea - pa), len_j = (double)(eb - pb);     // :1051-1058
                 const bool rev_i = (ra.y >> 31) != 0, rev_j = (rb.y >> 31) != 0;
@@ -460,7 +487,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 double mag_sq = 0.0;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {                                          // :1108-1113
-                    deltas[d] = load_pos<ATOMIC_LOADS>(ci + d) - load_pos<ATOMIC_LOADS>(cj + d);
+                    deltas[d] = load_pos<ATOMIC_LOADS>(ci + d * cs) - load_pos<ATOMIC_LOADS>(cj + d * cs);
                     mag_sq += deltas[d] * deltas[d];
                 }
                 if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }               // :1116-1119
@@ -472,8 +499,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int d = 0; d < D; ++d) {                                      // :1143-1149
                         double r_d = r * deltas[d];
-                        if (!same) add_pos(ci + d, -r_d);
-                        add_pos(cj + d, r_d);
+                        if (!same) add_pos(ci + d * cs, -r_d);
+                        add_pos(cj + d * cs, r_d);
                     }
                 } else {
 #pragma unroll
@@ -490,7 +517,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
             if (D >= 2) {
-                // the two adds of this lane: A = -r to end i, B = +r to end j (:1143-1149), re-dealt (issue_adds_regrouped)
+                // the two adds of this lane: A = -r to end i, B = +r to end j (:1143-1149)
                 double vA[D], vB[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) { vA[k] = -upd_r[k]; vB[k] = upd_r[k]; }
@@ -516,14 +543,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const int dst = lane + mshift;
                     fB = fB && (dst < 0 || dst > 63);                                  // partner beyond the run: add it myself
                 }
-                issue_adds_regrouped<D>(lane, vA, vB, pA, pB, fA, fB);
+                issue_adds<D>(cs, vA, vB, reinterpret_cast<double *>(pA), reinterpret_cast<double *>(pB), fA != 0, fB != 0);
             }
             if (wave_done >= wave_quota) break;                        // what is left of the pass is dropped (no carry-over in nD)
             if (!have_n) break;
             cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
         }
     }
-    a.rng[tid] = rng.s0; a.rng[T + tid] = rng.s1; a.rng[2 * T + tid] = rng.s2; a.rng[3 * T + tid] = rng.s3;
+    // (the stream's addresses are computed again here rather than kept in registers since the loads at the top: built for three
+    // waves per SIMD the kernel would otherwise spill exactly those four registers, and a kernel with scratch pays for its set-up)
+    uint32_t tid_out = tid;
+    asm volatile("" : "+v"(tid_out));
+    a.rng[tid_out] = rng.s0; a.rng[T + tid_out] = rng.s1; a.rng[2 * T + tid_out] = rng.s2; a.rng[3 * T + tid_out] = rng.s3;
     if (TRACE) a.trace_cnt[tid] = ntr;
     flush_counters(a, done, att);
 }
@@ -553,6 +584,9 @@ hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_load
     }
     return launch_nd_ref(dims, a, lds_tables, atomic_loads, trace, grid, block, lds, st);
 }
+
+// waves per SIMD the layout team kernels are built for (the host sizes the stream count by it)
+int nd_team_waves() { return GFS_ND_TEAM_WAVES; }
 
 // loads this translation unit's code object (HIP loads modules on first use); see gfs_warmup
 hipError_t warm_module_nd_team() {

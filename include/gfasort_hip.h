@@ -203,7 +203,7 @@ int   gfs_ctx_create(const gfs_graph_view *g, int device, gfs_ctx **out);
  * gfs_ctx_create).  Ranks of a multi-GPU run that all-reduce the device buffer in place must share
  * one layout.  Upload / download / trace always speak the ABI's dense indices and Layout.coords order;
  * only the raw device pointer (gfs_ctx_positions_device / gfs_ctx_bind_positions) is in device order:
- * 1D x[slot]; nD two end planes coords[end][slot][dim] (element-wise collectives do not care). */
+ * 1D x[slot]; nD the end x dimension planes coords[end][dim][slot] (element-wise collectives do not care). */
 int   gfs_ctx_create_with_layout(const gfs_graph_view *g, int device, const uint32_t *node_perm, gfs_ctx **out);
 int   gfs_ctx_node_layout(const gfs_ctx *ctx, uint32_t *perm_out, uint64_t n_nodes);
 void  gfs_ctx_destroy(gfs_ctx *ctx);

@@ -1018,6 +1018,95 @@ static int twin_trip_nd(gfo_state *s, const iter_state *it, const leader_t *ld, 
     return second;
 }
 
+/* Product: sgd_kernels_nd_team.hip fused_trip_nd — the layout form of the fused short-jump trip (D >= 2): a lane's step is
+ * the a-side of its own term in one colour and the b-side of its neighbour's in the other; it keeps the coordinates of its
+ * a-end and (when the run's two flips differ) of its b-end in registers, colour 1 computes on what colour 0 left there, and
+ * each of a lane's OWN ends receives ONE add for both colours, c + (-r + r'), not (c - r) + r'.  Partners beyond the trip
+ * are added per colour.  Coordinates in Layout order [node][end][dim].  Returns 0 when the quota filled between the colours. */
+static int fused_trip_nd(gfo_state *s, const iter_state *it, const leader_t *ld, uint64_t off, int64_t sh, int fa, int fb,
+                         uint64_t wave_first, uint64_t wave_quota, uint64_t *wave_done, double *c) {
+    const pidx *pi = &s->pi;
+    const uint64_t D = s->D;
+    const uint64_t z = (uint64_t)(sh < 0 ? -sh : sh);
+    uint64_t base = ld->ra0 + off;
+    if (base >= ld->cnt) base -= ld->cnt;
+    int out[64], term_ok[64], has_node[64], t_a[64] = {0}, t_b[64] = {0}; uint64_t grp[64], ia[64], ibo[64], ij[64];
+    double td[64], ca[64][GFO_MAX_DIMS], cb[64][GFO_MAX_DIMS], cp[64][GFO_MAX_DIMS], acc_a[64][GFO_MAX_DIMS], acc_b[64][GFO_MAX_DIMS];
+    for (int l = 0; l < 64; l++) {
+        const uint64_t sa = ld->first + base + (uint64_t)l, sb = (uint64_t)((int64_t)sa + sh);
+        const uint32_t node = pi->rec[sa].node, pnode = pi->rec[sb].node;
+        const int rev_own = (int)(pi->rec[sa].path_rev >> 31), rev_p = (int)(pi->rec[sb].path_rev >> 31);
+        out[l] = l + sh < 0 || l + sh > 63;
+        grp[l] = ((off + (uint64_t)l) / z) & 1;
+        has_node[l] = node != GFO_NO_NODE;
+        ia[l] = (uint64_t)(has_node[l] ? node : 0) * 2 + (uint64_t)(fa ? !rev_own : rev_own);      /* my a-end, my b-end */
+        ibo[l] = (uint64_t)(has_node[l] ? node : 0) * 2 + (uint64_t)(fb ? !rev_own : rev_own);
+        ij[l] = (uint64_t)(pnode != GFO_NO_NODE ? pnode : 0) * 2 + (uint64_t)(fb ? !rev_p : rev_p);  /* my partner's b-end */
+        uint64_t i2 = 0, j2 = 0;
+        term_ok[l] = nd_prepare(pi, sa, sb, fa, fb, &td[l], &i2, &j2);                 /* sgd.rs:1047-1103 */
+        for (uint64_t d = 0; d < D; d++) {
+            ca[l][d] = has_node[l] ? c[ia[l] * D + d] : 0.0;
+            cb[l][d] = has_node[l] && fa != fb ? c[ibo[l] * D + d] : 0.0;
+            cp[l][d] = out[l] && pnode != GFO_NO_NODE ? c[ij[l] * D + d] : 0.0;
+            acc_a[l][d] = 0.0; acc_b[l][d] = 0.0;
+        }
+    }
+    int second = 1;
+    for (uint64_t colour = 0; colour < 2; colour++) {
+        int valid[64]; double r[64][GFO_MAX_DIMS];
+        uint64_t nvalid = 0, rank = 0;
+        for (int l = 0; l < 64; l++) { valid[l] = term_ok[l] && grp[l] == colour; nvalid += (uint64_t)valid[l]; }
+        const uint64_t remaining = wave_quota - *wave_done;
+        for (int l = 0; l < 64; l++) {
+            s->att[wave_first + l]++;
+            if (valid[l] && rank++ >= remaining) valid[l] = 0;
+        }
+        *wave_done += nvalid < remaining ? nvalid : remaining;
+        for (int l = 0; l < 64; l++) {                                 /* every term of a colour reads the same snapshot */
+            for (uint64_t d = 0; d < D; d++) r[l][d] = 0.0;
+            if (!valid[l]) continue;
+            const double *cj = out[l] ? cp[l] : (fa != fb ? cb[l + sh] : ca[l + sh]);
+            const double mu = fmin(it->eta * (1.0 / td[l]), 1.0);                      /* :1085-1086 */
+            double deltas[GFO_MAX_DIMS], mag_sq = 0.0;
+            for (uint64_t d = 0; d < D; d++) { deltas[d] = ca[l][d] - cj[d]; mag_sq += deltas[d] * deltas[d]; }   /* :1108-1113 */
+            if (mag_sq == 0.0) { deltas[0] = 1e-9; mag_sq = 1e-18; }                   /* :1116-1119 */
+            const double mag = sqrt(mag_sq);                                           /* :1121 */
+            const double rr = (mu * (mag - td[l]) / 2.0) / mag;                        /* :1125, :1142 */
+            for (uint64_t d = 0; d < D; d++) r[l][d] = rr * deltas[d];
+            const uint64_t tg = wave_first + (uint64_t)l;
+            s->done[tg]++;                                                             /* :1151 */
+            if (s->trace && s->ntr[tg] < s->trace_per_stream) {
+                gfo_term *tr = &s->trace[tg * s->trace_per_stream + s->ntr[tg]++];
+                tr->i = (uint32_t)ia[l]; tr->j = (uint32_t)ij[l]; tr->d_ij = td[l];
+            }
+        }
+        for (int l = 0; l < 64; l++) {
+            const int src = l - (int)sh;
+            const int recv = src >= 0 && src <= 63 && valid[src];
+            if (valid[l] && ia[l] != ij[l]) {                                          /* :1143-1146 */
+                for (uint64_t d = 0; d < D; d++) { ca[l][d] = ca[l][d] - r[l][d]; acc_a[l][d] = t_a[l] ? acc_a[l][d] - r[l][d] : -r[l][d]; }
+                t_a[l] = 1;
+            }
+            if (recv) {                                                                /* :1147-1148 */
+                if (fa != fb) {
+                    for (uint64_t d = 0; d < D; d++) { cb[l][d] = cb[l][d] + r[src][d]; acc_b[l][d] = t_b[l] ? acc_b[l][d] + r[src][d] : r[src][d]; }
+                    t_b[l] = 1;
+                } else {
+                    for (uint64_t d = 0; d < D; d++) { ca[l][d] = ca[l][d] + r[src][d]; acc_a[l][d] = t_a[l] ? acc_a[l][d] + r[src][d] : r[src][d]; }
+                    t_a[l] = 1;
+                }
+            }
+            if (valid[l] && out[l]) for (uint64_t d = 0; d < D; d++) c[ij[l] * D + d] = c[ij[l] * D + d] + r[l][d];
+        }
+        if (colour == 0 && *wave_done >= wave_quota) { second = 0; break; }
+    }
+    for (int l = 0; l < 64; l++) {
+        if (t_a[l]) for (uint64_t d = 0; d < D; d++) c[ia[l] * D + d] = c[ia[l] * D + d] + acc_a[l][d];
+        if (t_b[l]) for (uint64_t d = 0; d < D; d++) c[ibo[l] * D + d] = c[ibo[l] * D + d] + acc_b[l][d];
+    }
+    return second;
+}
+
 /* Team semantics of the product (sgd1d_team_kernel): per wave of 64 streams, a PASS samples one
  * leader per stream; B TRIPS then expand the 64 leaders as 64/B runs of B lanes (trip t, run q
  * uses leader t*(64/B)+q).  Wave-level quota with a rank cut-off.  1D: the trips of a pass left over when
@@ -1097,11 +1186,14 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                     else GFO_ADVANCE(1);
                     continue;
                 }
-                if (s->D == 0 && RUNS == 1 && colour == 0 && two && !s->no_fused_trip) {
+                if ((s->D == 0 || s->D >= 2) && RUNS == 1 && colour == 0 && two && !s->no_fused_trip) {
                     const uint64_t off0 = run_offset(s, V[0].cnt, ktrips, V[0].ra0, V[0].rb0, seg);
                     const int64_t ms = merged_trip_shift(&V[0], off0);
-                    if (ms != 0) {                                      /* both colours in one trip (product: fused_trip) */
-                        if (!fused_trip_1d(s, &it, &V[0], off0, ms, wave_first, wave_quota, &wave_done, x))
+                    if (ms != 0) {                                      /* both colours in one trip (product: fused_trip / fused_trip_nd) */
+                        const int second = s->D ? fused_trip_nd(s, &it, &V[0], off0, ms, lead_fa[t], pp ? lead_fc[t] : lead_fb[t],
+                                                                wave_first, wave_quota, &wave_done, x)
+                                                : fused_trip_1d(s, &it, &V[0], off0, ms, wave_first, wave_quota, &wave_done, x);
+                        if (!second)
                             s->lead_colour[w] = 1;                      /* quota filled between the colours */
                         else GFO_ADVANCE(0);
                         continue;

@@ -254,29 +254,42 @@ def test_default_flags_on_drb1_tiled_in_series(shuffle_seed):
 
 def test_default_layout_flags_on_drb1_tiled_in_series():
     """`-p L --dimensions 2` on DRB1-3123 x120 (see the test above): the default layout kernel against reference streams from the
-    same start.  As for the sort, the reference's default schedule (--layout-iter 30) does not converge on this graph (relative
-    error 29 at path distance 1 for reference streams) and the run sampler is behind there — milder than in 1D: +12 % at distance
-    1, +9...13 % from 32 steps up (profiles/r03/layout_partner_probe.log; one partner per leader is no different) — and at
-    parity at three times the schedule (profiles/r03/tiled_layout_probe.log)."""
+    same starts.  ONE run of either sampler is not a yardstick on this graph: at --layout-iter 90 a run ends in one of two states,
+    ~9 % apart in stress and in every octave of path distance (reference streams: 0.2255, 0.2257, 0.2256, 0.2096 over four seeds;
+    the default kernel 0.2109, 0.2267, 0.2238, 0.2179 — profiles/r03/tiled_layout_seed_study.log; round 3's first form of this
+    test compared single runs and passed or failed by which state each had drawn).  So: four seeds each, the MEANS compared —
+    measured 0.92...1.045 per octave at 90 iterations.  As for the sort, the reference's default schedule (--layout-iter 30) does
+    not converge on this graph (relative error 29 at path distance 1 for reference streams) and the run sampler is behind there
+    — milder than in 1D: +12 % at distance 1, +9...13 % from 32 steps up (profiles/r03/layout_partner_probe.log)."""
     from gfasort_amd import sgd as S
     g = G.tile_series(load("DRB1-3123.gfa"), 120)
     og = oracle_graph(g)
     for iters in (90, 30):
-        p = P.LayoutSGDParams.from_graph(g, 2, 1)
-        p.iter_max = iters
-        c0 = S.default_layout_init(g, 2, p.seed)
-        rc, c_def, st = hip.path_linear_sgd_layout_raw(g, p, c0)
-        assert rc == 0 and st.bundle == 64 and st.term_updates == (p.iter_max + 1) * p.min_term_updates
-        rc, c_b1, st1 = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(flags=hip.F_BUNDLE(1)))
-        assert rc == 0 and st1.bundle == 1 and st1.term_updates == st.term_updates
+        stress, prof, e2e = {"def": [], "ref": []}, {"def": [], "ref": []}, {"def": [], "ref": []}
+        for seed in range(4):
+            p = P.LayoutSGDParams.from_graph(g, 2, 1)
+            p.iter_max = iters
+            p.seed = p.seed + 1000 * seed
+            c0 = S.default_layout_init(g, 2, p.seed)
+            rc, c_def, st = hip.path_linear_sgd_layout_raw(g, p, c0)
+            assert rc == 0 and st.bundle == 64 and st.term_updates == (p.iter_max + 1) * p.min_term_updates
+            rc, c_b1, st1 = hip.path_linear_sgd_layout_raw(g, p, c0, cfg=hip.make_config(flags=hip.F_BUNDLE(1)))
+            assert rc == 0 and st1.bundle == 1 and st1.term_updates == st.term_updates
+            for k, c in (("def", c_def), ("ref", c_b1)):
+                stress[k].append(O.layout_stress(og, 2, c, 2_000_000))
+                prof[k].append(_layout_profile(g, c, 2))
+                e2e[k].append(_end_to_end(g, c, 2))
+        s_def, s_ref = float(np.mean(stress["def"])), float(np.mean(stress["ref"]))
+        ratio = np.mean(prof["def"], axis=0) / np.mean(prof["ref"], axis=0)
+        (m_def, a_def), (m_ref, a_ref) = np.mean(e2e["def"], axis=0), np.mean(e2e["ref"], axis=0)
+        what = (iters, stress, " ".join(f"{v:.3f}" for v in ratio), (m_ref, a_ref), (m_def, a_def))
         if iters == 90:
-            # (stress and every octave at parity; the MEDIAN of |end-to-end distance - node length| is still 0.1 bp behind —
+            # (stress and every octave at parity; the MEDIAN of |end-to-end distance - node length| is still ~0.1 bp behind —
             # 1.01-1.16 against 0.90-1.01 bp, the mean 13.9 against 14.1 — the short-range side of the same lag)
-            _compare_layout(g, og, 2, c_b1, c_def, "DRB1 x120 --layout-iter 90, default layout flags vs GPU reference streams", tol_e2e=0.30)
+            assert s_def <= 1.10 * s_ref and ratio.max() <= 1.12, what
+            assert m_def <= 1.30 * m_ref + 0.02 and a_def <= 1.30 * a_ref + 0.02, what
         else:
-            s_ref, s_def = O.layout_stress(og, 2, c_b1, 2_000_000), O.layout_stress(og, 2, c_def, 2_000_000)
-            ratio = _layout_profile(g, c_def, 2) / _layout_profile(g, c_b1, 2)
-            assert s_def <= 1.12 * s_ref and ratio.max() <= 1.25, (s_ref, s_def, " ".join(f"{v:.3f}" for v in ratio))
+            assert s_def <= 1.12 * s_ref and ratio.max() <= 1.25, what
 
 
 def test_more_than_4_million_paths():
