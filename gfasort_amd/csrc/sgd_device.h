@@ -110,7 +110,7 @@ struct KArgs {
     uint32_t chain;                // longest run in trips (power of two; 1 = a run is one trip), see run_trips()
     uint32_t partners;             // partner draws per leader (1 or 2; 2 only for the 1D team kernel at B = 64), see Leader
     uint32_t ref_chunk;            // K1d / K2d: updates per live lane and pool claim (sgd_kernel_common.h ref_pooled_walk)
-    uint32_t dbg2;                 // more diagnostic bits (GFS_DBG2 environment variable): 1 = layout team kernels regroup their adds but do not issue them
+    uint32_t dbg2;                 // diagnostic bits for experiment builds (GFS_DBG2 environment variable); no kernel reads them at present
     uint32_t _pad5;
     IterConsts it;
 };
