@@ -67,6 +67,22 @@ __device__ __forceinline__ void flush_counters(const KArgs &a, uint32_t done, ui
     }
 }
 
+// The launch constants of the kernel, read afresh from the kernel-argument segment (every kernel here takes its KArgs first,
+// by value: offset 0).  The team kernels' sampler calls this once per pass (~1000 trips): scalar loads, and the ~40 scalar
+// registers of constants only the sampler needs are then free while the trips run — held through them they were spilled to
+// vector lanes and read back inside the trip machine (74 / 61 spilled in K2b / K1c).  The empty asm hides the pointer's
+// origin, or the loads would be hoisted and kept live like the by-value copy.
+__device__ __forceinline__ void reload_kargs(KArgs &as) {
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    typedef const __attribute__((address_space(4))) uint32_t kword;
+    kword *kw = (kword *)kp;
+    uint32_t *dw = reinterpret_cast<uint32_t *>(&as);
+    static_assert(sizeof(KArgs) % 4 == 0, "KArgs is copied by words");
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(KArgs) / 4; ++i) dw[i] = kw[i];
+}
+
 template <int B>
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int leader_lane) {
     if (B == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, leader_lane);     // wave-uniform leader

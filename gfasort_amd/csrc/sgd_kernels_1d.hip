@@ -361,7 +361,7 @@ __device__ __forceinline__ bool twin_trip(const KArgs &a, TeamState &ts, const T
 // One SGD iteration of one wave: passes and trips until the wave's quota is filled.
 template <int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path_tab, const double *zeta_tab,
-                                               TeamState &ts, const uint32_t tid, const uint64_t wave_quota) {
+                                               TeamState &ts, const uint32_t tid, const uint64_t wave_quota, const IterConsts *itp = nullptr) {
     const int lane = threadIdx.x & 63;
     const int sub = lane & (B - 1);
     const int q = lane / B;
@@ -371,7 +371,16 @@ __device__ __forceinline__ void team_iteration(const KArgs &a, const uint4 *path
     while (wave_done < wave_quota && passes < max_passes) {
         if (ts.left == 0 || ts.cool != (uint32_t)a.it.cooling) {
             ++passes;
-            ts.L = sample_leader<LDS_TABLES>(a, path_tab, zeta_tab, ts.rng);
+            // (the sampler reads its launch constants afresh — sgd_kernel_common.h reload_kargs — and, in a fused launch, the
+            // iteration's constants from the schedule in memory: itp)
+            KArgs as;
+            reload_kargs(as);
+            if (itp) {
+                const IterConsts *ip = itp;
+                asm volatile("" : "+s"(ip));
+                as.it = *ip;
+            }
+            ts.L = sample_leader<LDS_TABLES>(as, path_tab, zeta_tab, ts.rng);
             ts.left = B; ts.cool = (uint32_t)a.it.cooling; ts.colour = 0; ts.seg = 0; ts.p = 0;
         }
         const Leader &L = ts.L;
@@ -593,7 +602,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_fused_kern
             // the next claim travels while this chunk is worked on
             if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, cap - old < TEAM_CHUNK ? cap - old : TEAM_CHUNK);
+            team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, cap - old < TEAM_CHUNK ? cap - old : TEAM_CHUNK, its + k);
         }
     } else {
         // fixed quota per wave and iteration, free-running (GFS_F_DBG_FREE_RUNNING)
@@ -601,7 +610,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_fused_kern
         for (uint32_t k = 0; k < n_iters; ++k) {
             a.it = its[k];
             for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
-                team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK);
+                team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK, its + k);
         }
     }
     a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;

@@ -395,19 +395,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND
 
     while (wave_done < wave_quota && passes < max_passes) {
         ++passes;
-        // (the sampler reads its launch constants from the kernel-argument segment afresh in every pass — scalar loads, once per
-        // ~1000 trips — so that they do not sit in scalar registers through the trips: with them the trip machine spilled 74.)
+        // (the sampler reads its launch constants afresh: sgd_kernel_common.h reload_kargs)
         KArgs as;
-        {
-            auto kp = __builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(kp));
-            typedef const __attribute__((address_space(4))) uint32_t kword;
-            kword *kw = (kword *)kp;
-            uint32_t *dw = reinterpret_cast<uint32_t *>(&as);
-            static_assert(sizeof(KArgs) % 4 == 0, "KArgs is copied by words");
-#pragma unroll
-            for (unsigned i = 0; i < sizeof(KArgs) / 4; ++i) dw[i] = kw[i];
-        }
+        reload_kargs(as);
         const Leader L = sample_leader<LDS_TABLES>(as, path_tab, zeta_tab, rng);
         uint32_t lflips = rng.flip() | (rng.flip() << 1);                  // the run's end flips: bit 0 = a, bit 1 = b
         if (a.partners == 2u) lflips |= rng.flip() << 2;                   // bit 2 = the second partner's b
