@@ -198,8 +198,10 @@ def layout_leg(g, device_index, args, dims=2):
     launches = max(int(s1.launches - s0.launches), 1)
     kms = (s1.kernel_ms - s0.kernel_ms) / launches
     algo = 40 + 32 * dims                                  # 2 records x 16 B + 2 ends x D x (8 read + 8 write) + ...
-    out = {"value": upd / dt, "unit": "term-updates/s", "dimensions": dims, "steps": launches,
-           "sampling_bundle": int(s1.bundle), "run_trips": int(s1.run_trips), "avg_launch_ms": kms, "algorithmic_bytes_per_update": algo,
+    its = int(s1.iterations - s0.iterations)
+    out = {"value": upd / dt, "unit": "term-updates/s", "dimensions": dims, "steps": its, "launches": launches,
+           "sampling_bundle": int(s1.bundle), "run_trips": int(s1.run_trips), "avg_launch_ms": kms,
+           "kernel_ms_per_iteration": kms * launches / max(its, 1), "algorithmic_bytes_per_update": algo,
            "roofline_frac": (upd / launches) * algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     # the same launch against the memory-side atomic units (requests per update from the committed PMC pass of this kernel)
     try:

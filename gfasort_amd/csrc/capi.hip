@@ -32,6 +32,9 @@ hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables, int block, size_t 
 hipError_t warm_module_nd();
 hipError_t warm_module_nd_team();
 int nd_team_waves();
+hipError_t launch_nd_team_fused(int dims, const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
+                                dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t prepare_nd_team_fused(int dims, uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu);
 hipError_t warm_module_index();
 hipError_t init_positions_device(const uint32_t *d_node_len, const uint32_t *d_perm, double *d_x, uint64_t n);
 hipError_t reorder_positions_device(const double *d_src, double *d_dst, const uint32_t *d_perm, uint64_t N, uint32_t D,
@@ -320,7 +323,7 @@ struct gfs_ctx {
     double *d_zetas = nullptr; uint64_t zlen_full = 0, zlen_staged = 0;
     double *d_x = nullptr; bool x_owned = false; uint64_t x_len = 0;
     uint64_t *d_rng = nullptr;
-    uint32_t *d_lead = nullptr;      // 1D team kernels: the waves' partly expanded passes, [8][n_streams]
+    uint32_t *d_lead = nullptr;      // team kernels: the waves' partly expanded passes, [8][n_streams]
     unsigned long long *d_counters = nullptr;
     gfs_term *d_trace = nullptr; uint32_t *d_trace_cnt = nullptr;
     gfs::IterConsts *d_its = nullptr; uint64_t its_cap = 0;   // schedule slice of a fused launch (arbitrary lists)
@@ -556,9 +559,17 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
         const uint64_t resident = c->fused_resident_blocks * c->block;
         if (!c->cfg.n_streams && T > resident && resident >= 64) c->n_streams = T = resident;
     }
+    if ((dims == 2 || dims == 3) && c->bundle == 64) {
+        // the layout team kernel's fused launch (K2c): the same residency rule
+        int per_cu = 0;
+        HIPCHK(gfs::prepare_nd_team_fused(dims, c->bundle, c->lds_tables, (int)c->block, c->lds_bytes, &per_cu));
+        c->fused_resident_blocks = (uint64_t)std::max(per_cu, 0) * c->cu_count;
+        const uint64_t resident = c->fused_resident_blocks * c->block;
+        if (!c->cfg.n_streams && T > resident && resident >= 64) c->n_streams = T = resident;
+    }
 
     HIPCHK(hipMalloc(&c->d_rng, 4 * T * 8));
-    if (dims == 0 && c->bundle > 1) {
+    if (c->bundle > 1) {                                                 // team kernels, sort and layout
         HIPCHK(hipMalloc(&c->d_lead, 8 * T * sizeof(uint32_t)));
         HIPCHK(hipMemset(c->d_lead, 0, 8 * T * sizeof(uint32_t)));      // trips left = 0: no pass yet
     }
@@ -570,7 +581,7 @@ static int setup_common(gfs_ctx *c, const gfs_sgd_params *p, int dims, const gfs
     }
     rc = seed_streams(c);
     if (rc) return rc;
-    if (((dims == 0 && c->bundle >= 16) || c->bundle == 1) && c->params.iter_max < (1u << 20)) {
+    if (((dims == 0 && c->bundle >= 16) || ((dims == 2 || dims == 3) && c->bundle == 64) || c->bundle == 1) && c->params.iter_max < (1u << 20)) {
         // the whole schedule's per-iteration constants, for fused launches over consecutive iterations
         std::vector<gfs::IterConsts> all(c->params.iter_max + 1);
         for (uint64_t k = 0; k <= c->params.iter_max; ++k) iter_consts(c, k, all[k]);
@@ -913,8 +924,8 @@ int gfs_ctx_run_iteration(gfs_ctx *c, uint64_t k, void *hip_stream) {
     return GFS_OK;
 }
 
-// A range of iterations ks[0..n) (each in 0..=iter_max): ONE fused launch for the 1D team kernel (sgd1d_team_fused_kernel)
-// and for reference streams (sgd1d_fused_kernel, sgdnd_fused_kernel); otherwise one launch per iteration.
+// A range of iterations ks[0..n) (each in 0..=iter_max): ONE fused launch for the team kernels (sgd1d_team_fused_kernel; layouts of 2
+// and 3 dimensions: sgdnd_team_fused_kernel) and for reference streams (sgd1d_fused_kernel, sgdnd_fused_kernel); otherwise one launch per iteration.
 int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stream) {
     if (!c || (!ks && n)) return fail(GFS_E_ARG, "null argument");
     if (!c->configured) return fail(GFS_E_STATE, "context not set up");
@@ -928,16 +939,20 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     // rank on the same device can delay a workgroup, harmlessly under pools (a late wave finds the counters exhausted and
     // leaves), not so with fixed quotas.
     const uint64_t n_waves = (c->n_streams + 63) / 64;
-    const bool pool_ok = n_waves <= 0xFFFFFFFFull && c->quota_total / gfs::pool_slots((uint32_t)n_waves) < (1ull << 31);
+    // (layouts draw an iteration from ONE counter, sgd_kernels_nd_team.hip K2c: the whole iteration must stay below 2^31)
+    const bool pool_ok = n_waves <= 0xFFFFFFFFull &&
+                         c->quota_total / (c->dims != 0 && c->bundle > 1 ? 1u : gfs::pool_slots((uint32_t)n_waves)) < (1ull << 31);
     const bool free_running = (c->cfg.flags & GFS_F_DBG_FREE_RUNNING) != 0;
-    const bool team_fusable = c->dims == 0 && c->bundle >= 16 && (pool_ok || free_running) &&
+    const bool team_shape = (c->dims == 0 && c->bundle >= 16) || ((c->dims == 2 || c->dims == 3) && c->bundle == 64);   // K1c, K2c
+    const bool team_fusable = team_shape && (pool_ok || free_running) &&
                               (c->n_streams + c->block - 1) / c->block <= c->fused_resident_blocks;   // every workgroup resident
     const bool ref_fusable = c->bundle == 1 && pool_ok;
-    // (not a range of ONE iteration: an iteration is ~1.2 chunks per wave, so in a pooled launch of one iteration a fifth of the
-    // waves does two chunks while the others idle — 0.21 ms against the fixed quotas' 0.15-0.18 on C3; over many iterations the
-    // early finishers simply start the next one)
-    const bool can_fuse = (team_fusable || ref_fusable) && c->atomic_loads && !c->d_trace && n > 1 && n <= 0xFFFFFFFFull &&
-                          !(c->cfg.flags & GFS_F_NO_FUSE);
+    // (a range of ONE iteration only where an iteration is many chunks per wave: on C3, ~1.2 chunks per wave, a fifth of the waves of a
+    // pooled one-iteration launch does two chunks while the others idle — 0.21 ms against the fixed quotas' 0.15-0.18; a layout
+    // iteration of C4 is 16 chunks per wave, and drawn from the pool it ends for all waves at once)
+    const bool many_chunks = c->quota_total / n_waves >= 8ull * gfs::TEAM_CHUNK;
+    const bool can_fuse = (team_fusable || ref_fusable) && c->atomic_loads && !c->d_trace && (n > 1 || (n == 1 && team_fusable && many_chunks)) &&
+                          n <= 0xFFFFFFFFull && !(c->cfg.flags & GFS_F_NO_FUSE);
     if (!can_fuse) {
         for (uint64_t i = 0; i < n; ++i) { int rc = gfs_ctx_run_iteration(c, ks[i], hip_stream); if (rc) return rc; }
         return GFS_OK;
@@ -993,7 +1008,8 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     int rc = next_event_pair(c, ev);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev->first, st));                // (the event pair brackets the kernel alone)
-    hipError_t e = c->bundle > 1 ? gfs::launch_1d_fused(a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st)
+    hipError_t e = c->bundle > 1 ? (c->dims == 0 ? gfs::launch_1d_fused(a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st)
+                                                 : gfs::launch_nd_team_fused(c->dims, a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st))
                    : c->dims == 0 ? gfs::launch_1d_ref_fused(a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st)
                                   : gfs::launch_nd_ref_fused(c->dims, a, d_slice, (uint32_t)n, c->lds_tables, pool, grid, block, c->lds_bytes, st);
     if (e != hipSuccess) return fail(GFS_E_HIP, std::string("fused kernel launch: ") + hipGetErrorString(e));

@@ -368,40 +368,52 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
 #ifndef GFS_ND_TEAM_WAVES
 #define GFS_ND_TEAM_WAVES 3
 #endif
-template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND_TEAM_WAVES, GFS_ND_TEAM_WAVES))) sgdnd_team_kernel(const KArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const uint4 *path_tab; const double *zeta_tab;
-    stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
+// The wave's state across chunks, iterations and (through KArgs.lead) launches — as K1b's TeamState (sgd_kernels_1d.hip), plus the
+// run's end flips.
+struct NdTeamState {
+    Rng rng;
+    Leader L = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t lflips = 0;                                // the pass's end flips, per leader (bit 0: a, bit 1: b, bit 2: the second partner's b)
+    uint32_t left = 0, cool = 0, colour = 0, seg = 0, p = 0;
+    uint32_t done = 0, att = 0, ntr = 0;
+};
 
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= a.n_streams) return;
+// One CHUNK of one wave's work in an iteration: passes and trips until `wave_quota` updates are done.  Exactly K1b's
+// team_iteration: a pass outlives the chunk and the iteration it was sampled in and is dropped when the cooling phase changes;
+// a quota that fills between the two terms of a twin trip, or between the two colours of a fused one, leaves the second as the next
+// chunk's first trip (generic form); the rank cut-off that makes a count exact applies at the end of every chunk.  (Round 2's layout
+// kernel dropped what was left of a pass at the end of a launch and knew no chunks: with them an iteration can be drawn from a work
+// pool, K2c below.)
+template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__device__ __forceinline__ void nd_team_iteration(const KArgs &a, const uint4 *path_tab, const double *zeta_tab, NdTeamState &ts,
+                                                  const uint32_t tid, const uint64_t wave_quota, const IterConsts *itp = nullptr) {
     const int lane = threadIdx.x & 63;
     const int sub = lane & (B - 1);
     const int q = lane / B;
-    const uint64_t T = a.n_streams;
     const uint64_t cs = coord_step(a);
-    Rng rng;
-    rng.s0 = a.rng[tid]; rng.s1 = a.rng[T + tid]; rng.s2 = a.rng[2 * T + tid]; rng.s3 = a.rng[3 * T + tid];
-    // (readfirstlane: the wave's quota, and with it every loop variable of the trip machine, is then wave-uniform for the
-    // compiler too — scalar registers and scalar arithmetic instead of 64 copies, as in K1c)
-    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
-    uint64_t wave_quota = (uint64_t)a.quota_base * 64u;
-    if (wave_first < a.quota_rem) wave_quota += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
     const uint64_t max_passes = (uint64_t)a.attempt_factor * (wave_quota / (64u * B) + 1u) + 16u;
     uint64_t wave_done = 0, passes = 0;
-    uint32_t done = 0, att = 0;
-    uint32_t ntr = TRACE ? a.trace_cnt[tid] : 0;
-
     while (wave_done < wave_quota && passes < max_passes) {
-        ++passes;
-        // (the sampler reads its launch constants afresh: sgd_kernel_common.h reload_kargs)
-        KArgs as;
-        reload_kargs(as);
-        const Leader L = sample_leader<LDS_TABLES>(as, path_tab, zeta_tab, rng);
-        uint32_t lflips = rng.flip() | (rng.flip() << 1);                  // the run's end flips: bit 0 = a, bit 1 = b
-        if (a.partners == 2u) lflips |= rng.flip() << 2;                   // bit 2 = the second partner's b
-        int t = 0; uint32_t seg = 0, colour = 0, p = 0;
+        if (ts.left == 0 || ts.cool != (uint32_t)a.it.cooling) {
+            ++passes;
+            // (the sampler reads its launch constants afresh — sgd_kernel_common.h reload_kargs — and, in a fused launch, the
+            // iteration's constants from the schedule in memory: itp)
+            KArgs as;
+            reload_kargs(as);
+            if (itp) {
+                const IterConsts *ip = itp;
+                asm volatile("" : "+s"(ip));
+                as.it = *ip;
+            }
+            ts.L = sample_leader<LDS_TABLES>(as, path_tab, zeta_tab, ts.rng);
+            ts.lflips = ts.rng.flip() | (ts.rng.flip() << 1);             // the run's end flips: bit 0 = a, bit 1 = b
+            if (a.partners == 2u) ts.lflips |= ts.rng.flip() << 2;        // bit 2 = the second partner's b
+            ts.left = B; ts.cool = (uint32_t)a.it.cooling; ts.colour = 0; ts.seg = 0; ts.p = 0;
+        }
+        const Leader &L = ts.L;
+        const uint32_t lflips = ts.lflips;
+        int t = B - (int)ts.left;
+        uint32_t colour = ts.colour, seg = ts.seg, p = ts.p;
         TripND cur;
         expand_trip_nd<B, (D >= 2)>(a, L, lflips, t, seg, p, colour, sub, q, cur);
         for (;;) {
@@ -419,25 +431,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND
             TripND nxt;
             if (have_n) expand_trip_nd<B, (D >= 2)>(a, L, lflips, t_n, seg_n, p_n, colour_n, sub, q, nxt);
             if (D >= 2 && B == 64 && c_twin) {
-                if (!twin_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, done, att, ntr)) break;
+                if (!twin_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, ts.done, ts.att, ts.ntr)) {
+                    ts.colour = 0u; ts.seg = seg; ts.p = 1u;           // quota filled between the partners: the second one is
+                    break;                                             // the next chunk's first trip (generic form)
+                }
+                ts.colour = 0u; ts.seg = seg_n; ts.p = 0u;
+                if (t_n != t) --ts.left;
                 if (wave_done >= wave_quota || !have_n) break;
                 cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
                 continue;
             }
             if (D >= 2 && B == 64 && c_fused) {
-                // (a quota that fills between the colours ends the iteration: the pass is dropped in nD, and with it the
-                // second colour — as the generic form drops whatever is left of a pass)
-                if (!fused_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, done, att, ntr)) break;
+                if (!fused_trip_nd<D, ATOMIC_LOADS, TRACE>(a, cur, lane, tid, wave_quota, wave_done, ts.done, ts.att, ts.ntr)) {
+                    ts.colour = 1u; ts.seg = seg; ts.p = p;            // quota filled between the colours: the second one is
+                    break;                                             // the next chunk's first trip (generic form)
+                }
+                ts.colour = 0u; ts.seg = seg_n; ts.p = p_n;
+                if (t_n != t) --ts.left;
                 if (wave_done >= wave_quota || !have_n) break;
                 cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
                 continue;
             }
+            // consume the current trip (generic form)
+            ts.colour = colour_n; ts.seg = seg_n; ts.p = p_n;
+            if (t_n != t) --ts.left;
             bool valid = cur.valid;
             const uint4 ra = cur.ra, rb = cur.rb, na = cur.na, nb = cur.nb;
             const uint32_t qa = cur.qa, qb = cur.qb;
             const uint32_t cnt = cur.cnt, flips = cur.flips;
             const int mshift = cur.mshift;
-            ++att;
+            ++ts.att;
             double term_dist = 0.0;
             uint64_t idx_i = 0, idx_j = 0;
             bool oa = false, ob = false;
@@ -497,12 +520,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND
                     for (int d = 0; d < D; ++d) upd_r[d] = r * deltas[d];
                     upd_ci = ci; upd_cj = cj; upd_i = !same; upd_j = true;
                 }
-                ++done;                                                                // :1151
+                ++ts.done;                                                                // :1151
                 if (TRACE) {
-                    if (ntr < a.trace_per_stream) {
-                        TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ntr;
+                    if (ts.ntr < a.trace_per_stream) {
+                        TraceTerm *tt = reinterpret_cast<TraceTerm *>(a.trace) + (size_t)tid * a.trace_per_stream + ts.ntr;
                         tt->i = (uint32_t)idx_i; tt->j = (uint32_t)idx_j; tt->d = term_dist;
-                        ++ntr;
+                        ++ts.ntr;
                     }
                 }
             }
@@ -535,18 +558,128 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND
                 }
                 issue_adds<D>(cs, vA, vB, reinterpret_cast<double *>(pA), reinterpret_cast<double *>(pB), fA != 0, fB != 0);
             }
-            if (wave_done >= wave_quota) break;                        // what is left of the pass is dropped (no carry-over in nD)
+            if (wave_done >= wave_quota) break;                        // what is left of the pass serves the next chunk
             if (!have_n) break;
             cur = nxt; t = t_n; colour = colour_n; seg = seg_n; p = p_n;
         }
     }
+}
+
+// lead word (KArgs.lead[5]): as K1b's (sgd_kernels_1d.hip load_pass), with the pass's end flips in bits 5..7
+__device__ __forceinline__ void load_pass_nd(const KArgs &a, uint32_t tid, NdTeamState &ts) {
+    if (!a.lead) return;
+    const uint64_t T = a.n_streams;
+    ts.L.first_lo = a.lead[tid]; ts.L.first_hi = a.lead[T + tid]; ts.L.cnt = a.lead[2 * T + tid];
+    ts.L.ra0 = a.lead[3 * T + tid]; ts.L.rb0 = a.lead[4 * T + tid];
+    const uint32_t w = a.lead[5 * T + tid];
+    ts.L.ra1 = a.lead[6 * T + tid]; ts.L.rb1 = a.lead[7 * T + tid];
+    ts.L.ok = (w & 0x1Fu) | ((w >> 27) << 8);
+    ts.lflips = (w >> 5) & 7u;
+    const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);      // the place in the pass: the same for the whole wave
+    ts.left = (ws >> 8) & 0xFFu; ts.cool = (ws >> 16) & 1u; ts.colour = (ws >> 17) & 1u; ts.seg = (ws >> 18) & 0xFFu; ts.p = (ws >> 26) & 1u;
+}
+__device__ __forceinline__ void store_pass_nd(const KArgs &a, uint32_t tid, const NdTeamState &ts) {
+    if (!a.lead) return;
+    const uint64_t T = a.n_streams;
+    a.lead[tid] = ts.L.first_lo; a.lead[T + tid] = ts.L.first_hi; a.lead[2 * T + tid] = ts.L.cnt;
+    a.lead[3 * T + tid] = ts.L.ra0; a.lead[4 * T + tid] = ts.L.rb0;
+    a.lead[5 * T + tid] = (ts.L.ok & 0x1Fu) | ((ts.lflips & 7u) << 5) | (ts.left << 8) | (ts.cool << 16) | (ts.colour << 17) | (ts.seg << 18) |
+                          (ts.p << 26) | (((ts.L.ok >> 8) & 0x1Fu) << 27);
+    a.lead[6 * T + tid] = ts.L.ra1; a.lead[7 * T + tid] = ts.L.rb1;
+}
+
+// K2b: one launch = one iteration, a fixed quota per wave worked through in chunks (like a pool of its own: one wave is bit for
+// bit the oracle's mirror here and in K2c).
+template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND_TEAM_WAVES, GFS_ND_TEAM_WAVES))) sgdnd_team_kernel(const KArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= a.n_streams) return;
+    const uint64_t T = a.n_streams;
+    NdTeamState ts;
+    ts.rng.s0 = a.rng[tid]; ts.rng.s1 = a.rng[T + tid]; ts.rng.s2 = a.rng[2 * T + tid]; ts.rng.s3 = a.rng[3 * T + tid];
+    ts.ntr = TRACE ? a.trace_cnt[tid] : 0;
+    load_pass_nd(a, tid, ts);
+    // (readfirstlane: the wave's quota, and with it every loop variable of the trip machine, is then wave-uniform for the
+    // compiler too — scalar registers and scalar arithmetic instead of 64 copies, as in K1c)
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
+    uint64_t wq = (uint64_t)a.quota_base * 64u;
+    if (wave_first < a.quota_rem) wq += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
+    for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
+        nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK);
     // (the stream's addresses are computed again here rather than kept in registers since the loads at the top: built for three
-    // waves per SIMD the kernel would otherwise spill exactly those four registers, and a kernel with scratch pays for its set-up)
+    // waves per SIMD the kernel would otherwise spill exactly those registers, and a kernel with scratch pays for its set-up)
     uint32_t tid_out = tid;
     asm volatile("" : "+v"(tid_out));
-    a.rng[tid_out] = rng.s0; a.rng[T + tid_out] = rng.s1; a.rng[2 * T + tid_out] = rng.s2; a.rng[3 * T + tid_out] = rng.s3;
-    if (TRACE) a.trace_cnt[tid] = ntr;
-    flush_counters(a, done, att);
+    a.rng[tid_out] = ts.rng.s0; a.rng[T + tid_out] = ts.rng.s1; a.rng[2 * T + tid_out] = ts.rng.s2; a.rng[3 * T + tid_out] = ts.rng.s3;
+    if (TRACE) a.trace_cnt[tid] = ts.ntr;
+    store_pass_nd(a, tid_out, ts);
+    flush_counters(a, ts.done, ts.att);
+}
+
+// K2c: the same, FUSED over a range of iterations with WORK POOLS — K1c (sgd_kernels_1d.hip, which has the reasons) for layouts.
+// Fixed quotas leave a layout launch's waves finishing up to a fifth of the launch apart (a wave's trips cost by what its few
+// leaders happen to be; profiles/r03/nd_k_probe.log: the longer the runs, the fewer leaders per wave and the slower the launch);
+// drawn from a pool, an iteration ends for all waves within a chunk of each other, and the next one starts without a launch.
+template <int D, int B, bool LDS_TABLES, bool POOL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND_TEAM_WAVES, GFS_ND_TEAM_WAVES)))
+sgdnd_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters, uint32_t *pool) {
+    constexpr bool ATOMIC_LOADS = true;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint4 *path_tab; const double *zeta_tab;
+    stage_tables<LDS_TABLES>(a0, smem, path_tab, zeta_tab);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= a0.n_streams) return;
+    const uint64_t T = a0.n_streams;
+    KArgs a = a0;
+    NdTeamState ts;
+    ts.rng.s0 = a.rng[tid]; ts.rng.s1 = a.rng[T + tid]; ts.rng.s2 = a.rng[2 * T + tid]; ts.rng.s3 = a.rng[3 * T + tid];
+    const int lane = threadIdx.x & 63;
+    load_pass_nd(a, tid, ts);
+    if (POOL) {
+        // ONE counter per iteration for layouts.  K1c spreads an iteration over up to 16 counters so that the claims do not queue on
+        // one address; each is a fixed share of the iteration, so the waves of a fast counter run ahead of the others' — without
+        // bound over a schedule.  The sort does not notice; a layout does: on DRB1 x120 the median |distance between a node's two
+        // ends - its length| was 1.6 bp with 16 counters, 1.15 with one, 1.09 with a launch per iteration and 2.4 with free-running
+        // waves (reference streams 0.92; profiles/r03/tiled_layout_e2e_probe.log, nd_pool_slots_probe.log).  A layout chunk is
+        // 16 heavy trips, so one counter takes ~2e7 claims/s at most: 49.5 against 50.3 G updates/s on C4.
+        constexpr uint32_t slot = 0u;
+        const uint32_t cap = (uint32_t)((uint64_t)a0.quota_base * a0.n_streams + a0.quota_rem);   // the iteration's updates, < 2^31 (host-checked)
+        uint32_t k = 0, claim = 0;
+        a.it = its[0];
+        if (lane == 0) claim = __hip_atomic_fetch_add(pool + slot * POOL_STRIDE, TEAM_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (k < n_iters) {
+            const uint32_t old = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+            if (old >= cap) {                                          // this iteration's pool is exhausted
+                if (++k == n_iters) break;
+                a.it = its[k];                                         // wave-uniform: scalar loads
+                if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            // the next claim travels while this chunk is worked on
+            if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, cap - old < TEAM_CHUNK ? cap - old : TEAM_CHUNK, its + k);
+        }
+    } else {
+        // fixed quota per wave and iteration, free-running (GFS_F_DBG_FREE_RUNNING)
+        const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
+        uint64_t wq = (uint64_t)a.quota_base * 64u;
+        if (wave_first < a.quota_rem) wq += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
+        for (uint32_t k = 0; k < n_iters; ++k) {
+            a.it = its[k];
+            for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
+                nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK, its + k);
+        }
+    }
+    uint32_t tid_out = tid;
+    asm volatile("" : "+v"(tid_out));
+    a.rng[tid_out] = ts.rng.s0; a.rng[T + tid_out] = ts.rng.s1; a.rng[2 * T + tid_out] = ts.rng.s2; a.rng[3 * T + tid_out] = ts.rng.s3;
+    store_pass_nd(a, tid_out, ts);
+    flush_counters(a, ts.done, ts.att);
 }
 
 template <int D, int B>
@@ -573,6 +706,41 @@ hipError_t launch_nd(int dims, const KArgs &a, bool lds_tables, bool atomic_load
 #undef GFS_NDB_CASE
     }
     return launch_nd_ref(dims, a, lds_tables, atomic_loads, trace, grid, block, lds, st);
+}
+
+// K2c launchers: layouts of 2 and 3 dimensions at B = 64 (what the auto policy picks on graphs large enough for it to matter).
+// pool: zeroed counters, pool_bytes(n_iters) of them, or null (fixed quota per wave, free-running).
+template <int D>
+static hipError_t launch_nd_team_fused_d(const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables,
+                                         uint32_t *pool, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (pool) {
+        if (lds_tables) hipLaunchKernelGGL((sgdnd_team_fused_kernel<D, 64, true, true>), grid, block, lds, st, a, d_its, n_iters, pool);
+        else            hipLaunchKernelGGL((sgdnd_team_fused_kernel<D, 64, false, true>), grid, block, 0, st, a, d_its, n_iters, pool);
+    } else {
+        if (lds_tables) hipLaunchKernelGGL((sgdnd_team_fused_kernel<D, 64, true, false>), grid, block, lds, st, a, d_its, n_iters, pool);
+        else            hipLaunchKernelGGL((sgdnd_team_fused_kernel<D, 64, false, false>), grid, block, 0, st, a, d_its, n_iters, pool);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_nd_team_fused(int dims, const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
+                                dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    if (a.bundle != 64u) return hipErrorInvalidValue;
+    if (dims == 2) return launch_nd_team_fused_d<2>(a, d_its, n_iters, lds_tables, pool, grid, block, lds, st);
+    if (dims == 3) return launch_nd_team_fused_d<3>(a, d_its, n_iters, lds_tables, pool, grid, block, lds, st);
+    return hipErrorInvalidValue;
+}
+// workgroups of the fused kernel one CU holds at once (0: no fused kernel for this shape)
+template <int D>
+static hipError_t prepare_nd_team_fused_d(bool lds_tables, int block, size_t lds, int *blocks_per_cu) {
+    return lds_tables ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, sgdnd_team_fused_kernel<D, 64, true, true>, block, lds)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, sgdnd_team_fused_kernel<D, 64, false, true>, block, 0);
+}
+hipError_t prepare_nd_team_fused(int dims, uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu) {
+    *blocks_per_cu = 0;
+    if (bundle != 64u) return hipSuccess;
+    if (dims == 2) return prepare_nd_team_fused_d<2>(lds_tables, block, lds, blocks_per_cu);
+    if (dims == 3) return prepare_nd_team_fused_d<3>(lds_tables, block, lds, blocks_per_cu);
+    return hipSuccess;
 }
 
 // waves per SIMD the layout team kernels are built for (the host sizes the stream count by it)

@@ -599,6 +599,7 @@ struct gfo_state {
     int no_fused_trip;                                        /* mirror of GFS_F_DBG_NO_FUSED_TRIP */
     int partners, no_twin_trip;                               /* partner draws per leader (1, 2); mirror of GFS_F_DBG_NO_TWIN_TRIP */
     uint8_t *lead_p;                                          /* the partner each wave's next trip belongs to */
+    uint8_t *lead_flips;                                      /* nD: the end flips every leader of the pass drew (bit 0: a, 1: b, 2: the second partner's b) */
     uint32_t *node_slot;                                     /* bundled mode: the product's internal node layout (line-aligned runs) */
     gfo_term *trace; uint64_t trace_per_stream;
     uint64_t total_upd, total_att, iterations;
@@ -609,7 +610,7 @@ void gfo_state_destroy(gfo_state *s) {
     if (!s) return;
     pidx_free(&s->pi);
     free(s->etas); free(s->zetas); free(s->rng); free(s->done); free(s->att); free(s->ntr);
-    free(s->lead); free(s->lead_left); free(s->lead_cool); free(s->lead_colour); free(s->lead_seg); free(s->lead_p); free(s->node_slot);
+    free(s->lead); free(s->lead_left); free(s->lead_cool); free(s->lead_colour); free(s->lead_seg); free(s->lead_p); free(s->lead_flips); free(s->node_slot);
     free(s);
 }
 
@@ -1121,7 +1122,8 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
         const uint64_t wave_first = w * 64;
         uint64_t wave_quota = base * 64;
         if (wave_first < rem) wave_quota += (rem - wave_first) < 64 ? (rem - wave_first) : 64;
-        const int carry = s->D == 0;
+        const int carry = 1;        /* (round 2's layout kernel dropped what was left of a pass at the end of an iteration: the layout
+                                     * kernels now work in chunks and keep their passes exactly as the 1D ones do) */
         /* 1D: the wave works through its quota in chunks of GFO_TEAM_CHUNK updates, each with its own rank cut-off and pass
          * budget (product: sgd_device.h TEAM_CHUNK; its fused launch draws such chunks from a pool) */
         const uint64_t wave_quota_all = wave_quota;
@@ -1134,9 +1136,14 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
             s->lead_left = (uint8_t *)calloc(T / 64, 1); s->lead_cool = (uint8_t *)calloc(T / 64, 1);
             s->lead_colour = (uint8_t *)calloc(T / 64, 1); s->lead_seg = (uint8_t *)calloc(T / 64, 1);
             s->lead_p = (uint8_t *)calloc(T / 64, 1);
+            s->lead_flips = (uint8_t *)calloc(T, 1);
         }
         leader_t *L = s->lead + wave_first;
         int lead_fa[64] = {0}, lead_fb[64] = {0}, lead_fc[64] = {0};
+        for (int l = 0; l < 64; l++) {                                  /* (a pass outlives the chunk it was sampled in) */
+            const uint8_t f = s->lead_flips[wave_first + l];
+            lead_fa[l] = f & 1; lead_fb[l] = (f >> 1) & 1; lead_fc[l] = (f >> 2) & 1;
+        }
         while (wave_done < wave_quota && passes < max_passes) {
             if (!carry || s->lead_left[w] == 0 || s->lead_cool[w] != (uint8_t)it.cooling) {
                 passes++;
@@ -1146,6 +1153,7 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
                         lead_fa[l] = (int)flip(s->rng + 4 * (wave_first + l));
                         lead_fb[l] = (int)flip(s->rng + 4 * (wave_first + l));
                         if (s->partners == 2) lead_fc[l] = (int)flip(s->rng + 4 * (wave_first + l));   /* the second partner's b */
+                        s->lead_flips[wave_first + l] = (uint8_t)(lead_fa[l] | (lead_fb[l] << 1) | (lead_fc[l] << 2));
                     }
                 }
                 s->lead_left[w] = (uint8_t)B; s->lead_cool[w] = (uint8_t)it.cooling; s->lead_colour[w] = 0; s->lead_seg[w] = 0;

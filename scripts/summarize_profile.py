@@ -143,8 +143,8 @@ def main():
             # a profile of the layout launches: kept beside the headline kernel's figures, which stay as they are
             out["algorithmic_bytes_per_update"] = 104
             out["source"] = (os.path.basename(args.dst_prefix) + "_pmc_summary.csv (scripts/profile_nd.sh: rocprofv3 --pmc passes, one per "
-                             "counter group, over scripts/nd_pmc.py = BASELINE configs[3] `-p L --dimensions 2`, one launch = one "
-                             "iteration of 1e8 updates)")
+                             "counter group, over scripts/nd_pmc.py = BASELINE configs[3] `-p L --dimensions 2`, one fused launch of "
+                             "%d iterations of %g updates)" % (args.steps, args.updates))
             prev["layout_2d"] = out
             out = prev
         elif "layout_2d" in prev:

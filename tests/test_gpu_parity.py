@@ -755,6 +755,29 @@ def test_fused_launch_equals_per_iteration_launches_on_one_wave(bundle):
     assert np.array_equal(xf.view(np.uint64), xu.view(np.uint64))
 
 
+@pytest.mark.parametrize("dims", [2, 3])
+def test_fused_layout_launch_equals_per_iteration_launches_on_one_wave(dims):
+    """The same for the layout team kernel (K2c, sgdnd_team_fused_kernel): chunks, passes that outlive their iteration (KArgs.lead
+    carries them from launch to launch), one pool counter — one wave in ONE launch is bit for bit one launch per iteration."""
+    g = G.synth_windows(40_000, 8, 20_000, 12)
+    p = P.LayoutSGDParams.from_graph(g, dims, 1)
+    p.iter_max = 9
+    p.min_term_updates = 150_000
+    c0 = gaussian_init(g, dims, 5)
+    out = []
+    for extra in (0, hip.F_NO_FUSE):
+        ctx = hip.Context(g)
+        ctx.setup_nd(p, hip.make_config(n_streams=64, flags=hip.F_BUNDLE(64) | extra))
+        ctx.upload(c0)
+        ctx.run()
+        out.append((ctx.download(), ctx.stats()))
+        ctx.close()
+    (cf, sf), (cu, su) = out
+    assert (sf.launches, su.launches) == (1, 10) and sf.iterations == su.iterations == 10
+    assert (sf.term_updates, sf.attempts) == (su.term_updates, su.attempts) and sf.term_updates == 10 * p.min_term_updates
+    assert np.array_equal(cf.view(np.uint64), cu.view(np.uint64))
+
+
 def test_fused_range_with_repeated_and_partial_schedules():
     """run_range takes any list of iteration numbers (one fused launch per call — team kernel and reference streams alike);
     counts stay exact."""
@@ -1154,9 +1177,9 @@ def test_team_kernel_single_wave_positions_equal_the_oracle_mirror(graph, fused,
 @pytest.mark.parametrize("partners,twin", [(2, True), (2, False), (1, True)])
 @pytest.mark.parametrize("dims", [2, 3])
 def test_layout_team_kernel_single_wave_coords_equal_the_oracle_mirror(dims, partners, twin):
-    """The same for the layout kernels: one wave of sgdnd_team_kernel (end planes, one set of end flips per run, two partners
-    per leader with twin trips — or as two trips, or one partner —, lane-regrouped adds) against the oracle's sequential
-    mirror, coordinates bit for bit."""
+    """The same for the layout kernels: one wave of the layout team kernel in its fused launch (dimension planes, one set of end
+    flips per run, two partners per leader with twin trips — or as two trips, or one partner —, fused short-jump trips with one
+    add per end, chunks and passes that outlive their iteration) against the oracle's sequential mirror, coordinates bit for bit."""
     g = G.synth_windows(40_000, 8, 20_000, 12)
     p = P.LayoutSGDParams.from_graph(g, dims, 1)
     p.iter_max = 6
