@@ -223,9 +223,10 @@ int   gfs_ctx_reset_streams(gfs_ctx *ctx);                       /* re-seed RNG 
  * k > floor(cooling_start*iter_max) (sgd.rs:297,383-396).  Asynchronous on hip_stream
  * (a hipStream_t, NULL = the default stream).                                               */
 int   gfs_ctx_run_iteration(gfs_ctx *ctx, uint64_t k, void *hip_stream);
-/* iterations ks[0..n): ONE fused persistent launch (1D team kernel; reference streams in any dimension) in which the waves
- * walk the schedule and draw every iteration's exact number of updates from a shared pool; otherwise (layout team kernels,
- * traces, GFS_F_NO_FUSE) n launches.  Asynchronous.                                                                       */
+/* iterations ks[0..n): ONE fused persistent launch (the team kernels at their widest bundle: sorts, layouts of 2 and 3
+ * dimensions; reference streams in any dimension) in which the waves walk the schedule and draw every iteration's exact
+ * number of updates from a shared pool; otherwise (narrower bundles, traces, GFS_F_NO_FUSE, more streams than fit on the
+ * device at once, an iteration of >= 2^31 updates per pool counter) n launches.  Asynchronous.                            */
 int   gfs_ctx_run_range(gfs_ctx *ctx, const uint64_t *ks, uint64_t n, void *hip_stream);
 int   gfs_ctx_run(gfs_ctx *ctx, void *hip_stream);               /* k = 0..=iter_max (run_range), then sync */
 int   gfs_ctx_synchronize(gfs_ctx *ctx, void *hip_stream);
