@@ -221,8 +221,12 @@ def layout_leg(g, device_index, args, dims=2):
     for name, flags in (("default_flags", args.flags | hip.F_BUNDLE(args.bundle)), ("reference_streams", hip.F_BUNDLE(1))):
         rc, c, st = hip.path_linear_sgd_layout_raw(gb, pb, c0, cfg=hip.make_config(n_streams=args.streams, flags=flags, block_size=args.block))
         _, rms, _ = Q.stress_by_scale(gb, c, dims, 1_000_000)
+        cc = np.asarray(c).reshape(-1, 2, dims)
+        e2e = np.abs(np.sqrt(((cc[:, 0, :] - cc[:, 1, :]) ** 2).sum(axis=1)) - gb.node_len)     # |distance between a node's ends - its length|
         res[name] = {"value": st.term_updates / (st.kernel_ms * 1e-3), "unit": "term-updates/s", "sampling_bundle": int(st.bundle),
-                     "term_updates": int(st.term_updates), "layout_stress_2M_pairs": Q.sampled_stress(gb, c, dims, 2_000_000), "_rms": rms}
+                     "term_updates": int(st.term_updates), "launches": int(st.launches),
+                     "layout_stress_2M_pairs": Q.sampled_stress(gb, c, dims, 2_000_000),
+                     "node_end_to_end_error_bp_median_mean": [float(np.median(e2e)), float(np.mean(e2e))], "_rms": rms}
     ratio = res["default_flags"].pop("_rms") / res["reference_streams"].pop("_rms")
     out["bubbles_525k"] = dict(res, workload="synth_bubbles(400000,24,6), -p L --dimensions %d --layout-iter 30" % dims,
                                stress_ratio_default_over_reference_streams=res["default_flags"]["layout_stress_2M_pairs"] /
