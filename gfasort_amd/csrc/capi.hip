@@ -869,6 +869,7 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.partners = c->partners;
     a.dbg2 = 0;
     if (const char *e = std::getenv("GFS_DBG2")) a.dbg2 = (uint32_t)std::atol(e);
+    a.chunk = gfs::TEAM_CHUNK;
     a.ref_chunk = gfs::REF_CHUNK_PER_LANE;
     if (const char *e = std::getenv("GFS_DBG_REF_CHUNK")) { const long v = std::atol(e); if (v >= 1 && v <= 4096) a.ref_chunk = (uint32_t)v; }   // probe knob (scripts/ref_fused_probe.py)
     a.n_nodes = (uint32_t)c->n_nodes;
@@ -947,11 +948,18 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     const bool team_fusable = team_shape && (pool_ok || free_running) &&
                               (c->n_streams + c->block - 1) / c->block <= c->fused_resident_blocks;   // every workgroup resident
     const bool ref_fusable = c->bundle == 1 && pool_ok;
-    // (a range of ONE iteration only where an iteration is many chunks per wave: on C3, ~1.2 chunks per wave, a fifth of the waves of a
-    // pooled one-iteration launch does two chunks while the others idle — 0.21 ms against the fixed quotas' 0.15-0.18; a layout
-    // iteration of C4 is 16 chunks per wave, and drawn from the pool it ends for all waves at once)
-    const bool many_chunks = c->quota_total / n_waves >= 8ull * gfs::TEAM_CHUNK;
-    const bool can_fuse = (team_fusable || ref_fusable) && c->atomic_loads && !c->d_trace && (n > 1 || (n == 1 && team_fusable && many_chunks)) &&
+    // A range of ONE layout iteration is drawn from the pool too, in chunks short enough that every wave takes ~8 of them
+    // (256...2048 updates, a power of two: whole twin trips; below ~4 chunks of 256 per wave the launch keeps its fixed quotas).
+    // With fixed quotas a layout launch's waves finish as far apart as their leaders' costs are: C4 2.33 ms per iteration
+    // against 2.21 pooled (2.04 inside a fused range).  Not for the sort: its launches of one iteration are short (C3: 0.16 ms
+    // either way against 0.10 inside a fused range) — what they lose is the launch's ramp, not balance
+    // (profiles/r03/one_iteration_launch_probe.log).  Only this path shortens chunks: gfs_ctx_run_iteration and ranges of several
+    // iterations use 2048, which is what the oracle's mirror assumes unless told otherwise.
+    uint32_t one_chunk = gfs::TEAM_CHUNK;
+    const uint64_t per_wave = c->quota_total / n_waves;
+    while (one_chunk > 256u && per_wave < 8ull * one_chunk) one_chunk >>= 1;
+    const bool single_ok = team_fusable && pool_ok && c->dims != 0 && per_wave >= 4ull * one_chunk;
+    const bool can_fuse = (team_fusable || ref_fusable) && c->atomic_loads && !c->d_trace && (n > 1 || (n == 1 && single_ok)) &&
                           n <= 0xFFFFFFFFull && !(c->cfg.flags & GFS_F_NO_FUSE);
     if (!can_fuse) {
         for (uint64_t i = 0; i < n; ++i) { int rc = gfs_ctx_run_iteration(c, ks[i], hip_stream); if (rc) return rc; }
@@ -990,6 +998,7 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     }
     gfs::KArgs a{};
     fill_kargs(c, a);
+    if (n == 1 && c->bundle > 1) a.chunk = one_chunk;
     iter_consts(c, ks[0], a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
     // work pools (sgd_kernels_1d.hip): the waves draw an iteration's updates from shared counters, zeroed per launch

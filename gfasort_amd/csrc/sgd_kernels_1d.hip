@@ -536,8 +536,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_kernel(con
     ts.ntr = TRACE ? a.trace_cnt[tid] : 0;
     load_pass(a, tid, ts);
     const uint64_t wq = wave_quota_of(a, tid);                        // worked through in chunks, like a pool (K1c)
-    for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
-        team_iteration<B, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK);
+    for (uint64_t done = 0; done < wq; done += a.chunk)
+        team_iteration<B, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wq - done < a.chunk ? wq - done : a.chunk);
     a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;
     if (TRACE) a.trace_cnt[tid] = ts.ntr;
     store_pass(a, tid, ts);
@@ -589,28 +589,28 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_fused_kern
         const uint32_t cap = (uint32_t)(total / slots + (slot < total % slots ? 1u : 0u));   // < 2^31 (host-checked)
         uint32_t k = 0, claim = 0;
         a.it = its[0];
-        if (lane == 0) claim = __hip_atomic_fetch_add(pool + slot * POOL_STRIDE, TEAM_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) claim = __hip_atomic_fetch_add(pool + slot * POOL_STRIDE, a0.chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (k < n_iters) {
             const uint32_t old = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
             if (old >= cap) {                                          // this iteration's pool is exhausted
                 if (++k == n_iters) break;
                 a.it = its[k];                                         // wave-uniform: scalar loads
-                if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
+                if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, a0.chunk,
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 continue;
             }
             // the next claim travels while this chunk is worked on
-            if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
+            if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, a0.chunk,
                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, cap - old < TEAM_CHUNK ? cap - old : TEAM_CHUNK, its + k);
+            team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, cap - old < a0.chunk ? cap - old : a0.chunk, its + k);
         }
     } else {
         // fixed quota per wave and iteration, free-running (GFS_F_DBG_FREE_RUNNING)
         const uint64_t wq = wave_quota_of(a, tid);
         for (uint32_t k = 0; k < n_iters; ++k) {
             a.it = its[k];
-            for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
-                team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK, its + k);
+            for (uint64_t done = 0; done < wq; done += a.chunk)
+                team_iteration<B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq - done < a.chunk ? wq - done : a.chunk, its + k);
         }
     }
     a.rng[tid] = ts.rng.s0; a.rng[T + tid] = ts.rng.s1; a.rng[2 * T + tid] = ts.rng.s2; a.rng[3 * T + tid] = ts.rng.s3;

@@ -607,8 +607,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND
     const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
     uint64_t wq = (uint64_t)a.quota_base * 64u;
     if (wave_first < a.quota_rem) wq += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
-    for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
-        nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK);
+    for (uint64_t done = 0; done < wq; done += a.chunk)
+        nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, TRACE>(a, path_tab, zeta_tab, ts, tid, wq - done < a.chunk ? wq - done : a.chunk);
     // (the stream's addresses are computed again here rather than kept in registers since the loads at the top: built for three
     // waves per SIMD the kernel would otherwise spill exactly those registers, and a kernel with scratch pays for its set-up)
     uint32_t tid_out = tid;
@@ -649,20 +649,20 @@ sgdnd_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_
         const uint32_t cap = (uint32_t)((uint64_t)a0.quota_base * a0.n_streams + a0.quota_rem);   // the iteration's updates, < 2^31 (host-checked)
         uint32_t k = 0, claim = 0;
         a.it = its[0];
-        if (lane == 0) claim = __hip_atomic_fetch_add(pool + slot * POOL_STRIDE, TEAM_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) claim = __hip_atomic_fetch_add(pool + slot * POOL_STRIDE, a0.chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (k < n_iters) {
             const uint32_t old = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
             if (old >= cap) {                                          // this iteration's pool is exhausted
                 if (++k == n_iters) break;
                 a.it = its[k];                                         // wave-uniform: scalar loads
-                if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
+                if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, a0.chunk,
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 continue;
             }
             // the next claim travels while this chunk is worked on
-            if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, TEAM_CHUNK,
+            if (lane == 0) claim = __hip_atomic_fetch_add(pool + ((size_t)k * POOL_SLOTS + slot) * POOL_STRIDE, a0.chunk,
                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, cap - old < TEAM_CHUNK ? cap - old : TEAM_CHUNK, its + k);
+            nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, cap - old < a0.chunk ? cap - old : a0.chunk, its + k);
         }
     } else {
         // fixed quota per wave and iteration, free-running (GFS_F_DBG_FREE_RUNNING)
@@ -671,8 +671,8 @@ sgdnd_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_
         if (wave_first < a.quota_rem) wq += (a.quota_rem - wave_first) < 64u ? (a.quota_rem - wave_first) : 64u;
         for (uint32_t k = 0; k < n_iters; ++k) {
             a.it = its[k];
-            for (uint64_t done = 0; done < wq; done += TEAM_CHUNK)
-                nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq - done < TEAM_CHUNK ? wq - done : TEAM_CHUNK, its + k);
+            for (uint64_t done = 0; done < wq; done += a.chunk)
+                nd_team_iteration<D, B, LDS_TABLES, ATOMIC_LOADS, false>(a, path_tab, zeta_tab, ts, tid, wq - done < a.chunk ? wq - done : a.chunk, its + k);
         }
     }
     uint32_t tid_out = tid;

@@ -597,6 +597,7 @@ struct gfo_state {
     uint64_t chain;                                           /* longest run in trips (B = 64); mirror of GFS_F_CHAIN */
     int one_colour;                                           /* mirror of GFS_F_DBG_ONE_COLOUR */
     int no_fused_trip;                                        /* mirror of GFS_F_DBG_NO_FUSED_TRIP */
+    uint64_t chunk;                                           /* updates per chunk of a team wave's work (product: KArgs.chunk; default GFO_TEAM_CHUNK) */
     int partners, no_twin_trip;                               /* partner draws per leader (1, 2); mirror of GFS_F_DBG_NO_TWIN_TRIP */
     uint8_t *lead_p;                                          /* the partner each wave's next trip belongs to */
     uint8_t *lead_flips;                                      /* nD: the end flips every leader of the pass drew (bit 0: a, 1: b, 2: the second partner's b) */
@@ -623,7 +624,7 @@ int gfo_state_create(const gfo_graph *g, const gfo_params *p, const double *etas
     gfo_state *s = (gfo_state *)calloc(1, sizeof *s);
     if (!s) return -2;
     if (pidx_build(g, 1, &s->pi)) { gfo_state_destroy(s); return -2; }
-    s->p = *p; s->T = n_streams; s->D = dims; s->bundle = 1; s->chain = 1; s->partners = 1;
+    s->p = *p; s->T = n_streams; s->D = dims; s->bundle = 1; s->chain = 1; s->partners = 1; s->chunk = 0;
     s->quota_total = quota_total ? quota_total : p->min_term_updates;
     s->attempt_factor = attempt_factor ? attempt_factor : 64;
     s->etas = (double *)malloc((p->iter_max + 1) * 8);
@@ -707,6 +708,13 @@ int gfo_state_set_one_colour(gfo_state *s, int on) {
 int gfo_state_set_partners(gfo_state *s, int partners, int no_twin) {
     if (!s || (partners != 1 && partners != 2)) return -1;
     s->partners = partners; s->no_twin_trip = no_twin ? 1 : 0;
+    return 0;
+}
+
+/* updates per chunk (product: a pooled launch of ONE small iteration works in chunks of 256...2048, capi.hip gfs_ctx_run_range) */
+int gfo_state_set_chunk(gfo_state *s, uint64_t chunk) {
+    if (!s || chunk == 0) return -1;
+    s->chunk = chunk;
     return 0;
 }
 
@@ -1127,8 +1135,9 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
         /* 1D: the wave works through its quota in chunks of GFO_TEAM_CHUNK updates, each with its own rank cut-off and pass
          * budget (product: sgd_device.h TEAM_CHUNK; its fused launch draws such chunks from a pool) */
         const uint64_t wave_quota_all = wave_quota;
-        for (uint64_t chunk0 = 0; chunk0 < wave_quota_all; chunk0 += (carry ? GFO_TEAM_CHUNK : wave_quota_all)) {
-        if (carry) wave_quota = wave_quota_all - chunk0 < GFO_TEAM_CHUNK ? wave_quota_all - chunk0 : GFO_TEAM_CHUNK;
+        const uint64_t CH = s->chunk ? s->chunk : GFO_TEAM_CHUNK;
+        for (uint64_t chunk0 = 0; chunk0 < wave_quota_all; chunk0 += (carry ? CH : wave_quota_all)) {
+        if (carry) wave_quota = wave_quota_all - chunk0 < CH ? wave_quota_all - chunk0 : CH;
         const uint64_t max_passes = s->attempt_factor * (wave_quota / (64 * B) + 1) + 16;
         uint64_t wave_done = 0, passes = 0;
         if (!s->lead) {

@@ -129,6 +129,7 @@ int  gfo_state_set_bundle(gfo_state *s, uint64_t bundle);
 int  gfo_state_set_chain(gfo_state *s, uint64_t chain);  /* mirror of GFS_F_CHAIN: longest run in trips (B = 64, 1D) */
 int  gfo_state_set_one_colour(gfo_state *s, int on);   /* mirror of GFS_F_DBG_ONE_COLOUR */
 int  gfo_state_set_no_fused_trip(gfo_state *s, int on); /* mirror of GFS_F_DBG_NO_FUSED_TRIP (1D) */
+int  gfo_state_set_chunk(gfo_state *s, uint64_t chunk); /* updates per chunk of a team wave's work (product: KArgs.chunk) */
 int  gfo_state_set_partners(gfo_state *s, int partners, int no_twin);   /* partner draws per leader (product default at B = 64
                                                                            in 1D: 2); no_twin: mirror of GFS_F_DBG_NO_TWIN_TRIP */
 /* bundled mode: the product's internal node layout (slot of dense node k), to mirror its line-aligned runs; NULL = identity */

@@ -242,7 +242,7 @@ class State:
     """Resumable deterministic run (gfo_state).  bundle > 1 mirrors the product's bundled sampler."""
 
     def __init__(self, g, p, dims=0, n_streams=1, stream_base=0, quota_total=0, attempt_factor=64,
-                 trace_per_stream=0, bundle=1, etas=None, zts=None, node_slots=None, one_colour=False, chain=1, fused_trip=True, partners=1, twin_trip=True):
+                 trace_per_stream=0, bundle=1, etas=None, zts=None, node_slots=None, one_colour=False, chain=1, fused_trip=True, partners=1, twin_trip=True, chunk=0):
         self.g, self.p = g, p
         self.trace = np.zeros(n_streams * trace_per_stream, dtype=TERM_DTYPE) if trace_per_stream else None
         self.h = C.c_void_p()
@@ -260,6 +260,9 @@ class State:
             assert lib().gfo_state_set_partners(self.h, C.c_int(partners), C.c_int(0 if twin_trip else 1)) == 0
         if not fused_trip:
             assert lib().gfo_state_set_no_fused_trip(self.h, C.c_int(1)) == 0       # mirror of GFS_F_DBG_NO_FUSED_TRIP
+        if chunk:
+            # updates per chunk of a team wave's work (the product shortens it for a pooled launch of ONE small iteration)
+            assert lib().gfo_state_set_chunk(self.h, C.c_uint64(chunk)) == 0
         if chain != 1:
             # the product's long runs (GFS_F_CHAIN; its default at B = 64 is 64)
             assert lib().gfo_state_set_chain(self.h, C.c_uint64(chain)) == 0
