@@ -31,7 +31,7 @@ hipError_t warm_module_1d();
 hipError_t prepare_1d_fused(uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu);
 hipError_t warm_module_nd();
 hipError_t warm_module_nd_team();
-int nd_team_waves();
+int nd_team_waves(int dims);
 hipError_t launch_nd_team_fused(int dims, const KArgs &a, const IterConsts *d_its, uint32_t n_iters, bool lds_tables, uint32_t *pool,
                                 dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t prepare_nd_team_fused(int dims, uint32_t bundle, bool lds_tables, int block, size_t lds, int *blocks_per_cu);
@@ -418,9 +418,9 @@ static uint64_t auto_stream_count(const gfs_ctx *c, bool team) {
     // lanes per CU; 5 waves (96 VGPRs) spill 58 registers and are slower (profiles/r02/two_partners.log).  The fused launch
     // further bounds the count by the workgroups that are resident at once (setup_common).
     // The layout team kernels live on registers (a twin trip holds six records and three ends' coordinates): built for 3 waves
-    // per SIMD (165 VGPRs at D = 2, nothing spilled) = 768 lanes per CU (sgd_kernels_nd_team.hip nd_team_waves; round 2's
-    // kernel needed 203 and ran two).
-    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1024 : (team && c->dims >= 2) ? 256u * (unsigned)gfs::nd_team_waves() : 976);
+    // per SIMD (165 VGPRs at D = 2, nothing spilled) = 768 lanes per CU, for 2 at D = 3 (176) = 512 (sgd_kernels_nd_team.hip
+    // nd_team_waves; round 2's kernel needed 203 and ran two).
+    const uint64_t chip = (uint64_t)c->cu_count * ((team && c->dims == 0) ? 1024 : (team && c->dims >= 2) ? 256u * (unsigned)gfs::nd_team_waves(c->dims) : 976);
     // keep >= 8 updates per stream per batch on small graphs
     const uint64_t by_work = ((c->quota_total + 7) / 8 + 63) / 64 * 64;
     // and never more than one stream per 4 nodes (<= 0.5 in-flight terms per node): every in-flight

@@ -359,7 +359,7 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
     return second;
 }
 
-// (3 waves per SIMD, <= 168 VGPRs: 165 at D = 2, nothing spilled; D = 3 spills four cold ones.  Round 2's kernel needed ~210 and ran
+// (3 waves per SIMD, <= 168 VGPRs: 165 at D = 2, nothing spilled; D = 3: two waves, 176, see nd_waves_for.  Round 2's kernel needed ~210 and ran
 // two waves — a twin trip holds the records of three steps and of the steps after them, the next trip's too, and three ends'
 // coordinates.  What brought it under 168: the trip machine's state in scalar registers (uni), steps as 32-bit ranks in their
 // path, no lane permutes for the adds (dimension planes), the sampler's constants re-read per pass.  Three waves hide the
@@ -368,6 +368,9 @@ __device__ __forceinline__ bool twin_trip_nd(const KArgs &a, const TripND &cur, 
 #ifndef GFS_ND_TEAM_WAVES
 #define GFS_ND_TEAM_WAVES 3
 #endif
+// (D = 3 holds half as many coordinates again: three waves' worth of registers spill 4-11 of them, and under the work pool two
+// waves are as fast — 34.2 against 34.3 G updates/s on C4, profiles/r03/nd_k_probe_fused.log — so D = 3 is built for two.)
+constexpr int nd_waves_for(int dims) { return dims >= 3 ? 2 : GFS_ND_TEAM_WAVES; }
 // The wave's state across chunks, iterations and (through KArgs.lead) launches — as K1b's TeamState (sgd_kernels_1d.hip), plus the
 // run's end flips.
 struct NdTeamState {
@@ -591,7 +594,7 @@ __device__ __forceinline__ void store_pass_nd(const KArgs &a, uint32_t tid, cons
 // K2b: one launch = one iteration, a fixed quota per wave worked through in chunks (like a pool of its own: one wave is bit for
 // bit the oracle's mirror here and in K2c).
 template <int D, int B, bool LDS_TABLES, bool ATOMIC_LOADS, bool TRACE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND_TEAM_WAVES, GFS_ND_TEAM_WAVES))) sgdnd_team_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nd_waves_for(D), nd_waves_for(D)))) sgdnd_team_kernel(const KArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint4 *path_tab; const double *zeta_tab;
     stage_tables<LDS_TABLES>(a, smem, path_tab, zeta_tab);
@@ -624,7 +627,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND
 // leaders happen to be; profiles/r03/nd_k_probe.log: the longer the runs, the fewer leaders per wave and the slower the launch);
 // drawn from a pool, an iteration ends for all waves within a chunk of each other, and the next one starts without a launch.
 template <int D, int B, bool LDS_TABLES, bool POOL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFS_ND_TEAM_WAVES, GFS_ND_TEAM_WAVES)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nd_waves_for(D), nd_waves_for(D))))
 sgdnd_team_fused_kernel(const KArgs a0, const IterConsts *its, const uint32_t n_iters, uint32_t *pool) {
     constexpr bool ATOMIC_LOADS = true;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -744,7 +747,7 @@ hipError_t prepare_nd_team_fused(int dims, uint32_t bundle, bool lds_tables, int
 }
 
 // waves per SIMD the layout team kernels are built for (the host sizes the stream count by it)
-int nd_team_waves() { return GFS_ND_TEAM_WAVES; }
+int nd_team_waves(int dims) { return nd_waves_for(dims); }
 
 // loads this translation unit's code object (HIP loads modules on first use); see gfs_warmup
 hipError_t warm_module_nd_team() {
