@@ -1,5 +1,5 @@
-// sgd_kernels_nd_team.hip — K2b: team (bundled) kernels of path_linear_sgd_layout, D = 1..3, and the
-// nD launch dispatcher.
+// sgd_kernels_nd_team.hip — K2b / K2c: team (bundled) kernels of path_linear_sgd_layout, D = 1..3 (one launch per iteration;
+// the fused pooled launch of a range of iterations for D = 2, 3 at B = 64), and the nD launch dispatcher.
 #include "sgd_kernel_common.h"
 
 namespace gfs {
@@ -16,7 +16,7 @@ hipError_t launch_nd_ref(int dims, const KArgs &a, bool lds_tables, bool atomic_
 // updates 8*B CONTIGUOUS bytes per side and dimension: half the atomic requests and half the coordinate
 // lines of per-lane flips (measured: 1.08 -> 0.55 requests per update for D = 2, the atomic unit being
 // what binds this kernel).  Node lengths come from the following step record as in K2.  Atomics are
-// issued in the trip that computes them (no deferral).
+// issued in the trip that computes them (no deferral beyond the trip: a fused or twin trip adds once per end).
 // ------------------------------------------------------------------------------------------
 // One trip = (slot t of the pass, trip seg of its run, colour) — as in K1b (sgd_kernels_1d.hip): long runs for B = 64
 // (sgd_device.h run_trips) and two colours for jumps shorter than the run (two_colour).
