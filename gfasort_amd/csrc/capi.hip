@@ -948,17 +948,19 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     const bool team_fusable = team_shape && (pool_ok || free_running) &&
                               (c->n_streams + c->block - 1) / c->block <= c->fused_resident_blocks;   // every workgroup resident
     const bool ref_fusable = c->bundle == 1 && pool_ok;
-    // A range of ONE layout iteration is drawn from the pool too, in chunks short enough that every wave takes ~8 of them
-    // (256...2048 updates, a power of two: whole twin trips; below ~4 chunks of 256 per wave the launch keeps its fixed quotas).
-    // With fixed quotas a layout launch's waves finish as far apart as their leaders' costs are: C4 2.33 ms per iteration
-    // against 2.21 pooled (2.04 inside a fused range).  Not for the sort: its launches of one iteration are short (C3: 0.16 ms
-    // either way against 0.10 inside a fused range) — what they lose is the launch's ramp, not balance
-    // (profiles/r03/one_iteration_launch_probe.log).  Only this path shortens chunks: gfs_ctx_run_iteration and ranges of several
-    // iterations use 2048, which is what the oracle's mirror assumes unless told otherwise.
+    // A range of ONE layout iteration is drawn from the pool too where it is many chunks per wave: with fixed quotas a layout
+    // launch's waves finish as far apart as their leaders' costs are (C4: 2.33 ms per iteration against 2.21 pooled, 2.04 inside
+    // a fused range).  Not with shorter chunks for smaller iterations: the layout pool is ONE counter, and it takes ~2e7 claims/s
+    // comfortably and 4e7 not (C4 in chunks of 1024 / 512 / 256: 2.41 / 3.05 / 5.24 ms).  Not for the sort either: its launches of
+    // one iteration are short (C3: 0.16 ms with fixed quotas, 0.15 pooled in chunks of 1024, 0.10 inside a fused range)
+    // (profiles/r03/one_iteration_launch_probe.log, launch_overhead_probe.log).
     uint32_t one_chunk = gfs::TEAM_CHUNK;
     const uint64_t per_wave = c->quota_total / n_waves;
-    while (one_chunk > 256u && per_wave < 8ull * one_chunk) one_chunk >>= 1;
-    const bool single_ok = team_fusable && pool_ok && c->dims != 0 && per_wave >= 4ull * one_chunk;
+    bool single_ok = team_fusable && pool_ok && c->dims != 0 && per_wave >= 8ull * one_chunk;
+    if (const char *e = std::getenv("GFS_DBG_ONE_CHUNK")) {               // probe knob (scripts/one_iteration_launch_probe.py): also for the sort
+        const long v = std::atol(e);
+        if (v >= 64 && v <= 4096 && !(v & (v - 1))) { one_chunk = (uint32_t)v; single_ok = team_fusable && pool_ok; }
+    }
     const bool can_fuse = (team_fusable || ref_fusable) && c->atomic_loads && !c->d_trace && (n > 1 || (n == 1 && single_ok)) &&
                           n <= 0xFFFFFFFFull && !(c->cfg.flags & GFS_F_NO_FUSE);
     if (!can_fuse) {

@@ -111,7 +111,7 @@ struct KArgs {
     uint32_t partners;             // partner draws per leader (1 or 2; 2 only for the 1D team kernel at B = 64), see Leader
     uint32_t ref_chunk;            // K1d / K2d: updates per live lane and pool claim (sgd_kernel_common.h ref_pooled_walk)
     uint32_t dbg2;                 // diagnostic bits for experiment builds (GFS_DBG2 environment variable); no kernel reads them at present
-    uint32_t chunk;                // updates per chunk of a team wave's work (TEAM_CHUNK; smaller for a pooled launch of ONE small iteration)
+    uint32_t chunk;                // updates per chunk of a team wave's work (TEAM_CHUNK; the probe knob GFS_DBG_ONE_CHUNK changes it)
     IterConsts it;
 };
 
@@ -274,7 +274,7 @@ __device__ __forceinline__ uint32_t leader_ok(uint32_t okw, uint32_t p) { return
 // The kernel is bound by the memory side's atomic units, then by HBM bytes; this takes a quarter off both.
 // A team wave works through an iteration in CHUNKS of this many updates (sgd_kernels_1d.hip, work pools); the rank cut-off
 // that makes a count exact applies at the end of every chunk.  2048 = 32 full trips.
-constexpr uint32_t TEAM_CHUNK = 2048;        // (the default of KArgs.chunk; 256...2048 where the host shortens it: capi.hip gfs_ctx_run_range)
+constexpr uint32_t TEAM_CHUNK = 2048;        // (the value of KArgs.chunk unless a probe says otherwise: capi.hip gfs_ctx_run_range)
 
 // LONG RUNS.  A leader is expanded not over one trip but over K consecutive trips of its wave: trip `seg` takes the
 // steps seg*B .. seg*B+B-1 further along the path, all with the leader's jump, so a run is K*B consecutive steps.

@@ -227,7 +227,7 @@ int   gfs_ctx_run_iteration(gfs_ctx *ctx, uint64_t k, void *hip_stream);
  * dimensions; reference streams in any dimension) in which the waves walk the schedule and draw every iteration's exact
  * number of updates from a shared pool; otherwise (narrower bundles, traces, GFS_F_NO_FUSE, more streams than fit on the
  * device at once, an iteration of >= 2^31 updates per pool counter) n launches.  A range of ONE layout iteration is pooled
- * as well (in shorter chunks; gfs_ctx_run_iteration keeps a fixed quota per wave).  Asynchronous.                        */
+ * as well where it is many chunks per wave (gfs_ctx_run_iteration keeps a fixed quota per wave).  Asynchronous.         */
 int   gfs_ctx_run_range(gfs_ctx *ctx, const uint64_t *ks, uint64_t n, void *hip_stream);
 int   gfs_ctx_run(gfs_ctx *ctx, void *hip_stream);               /* k = 0..=iter_max (run_range), then sync */
 int   gfs_ctx_synchronize(gfs_ctx *ctx, void *hip_stream);

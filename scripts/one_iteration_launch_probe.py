@@ -17,9 +17,15 @@ for dims in (0, 2):
     ctx.setup_nd(p, hip.make_config()) if dims else ctx.setup_1d(p, hip.make_config())
     x0 = S.default_layout_init(g, dims, p.seed).ravel() if dims else hip.init_positions(g)
     ks = list(range(1, 21))
-    for name, fn in (("fixed quotas, one launch per iteration", lambda: [ctx.run_iteration(k) for k in ks]),
-                     ("pooled, one launch per iteration", lambda: [ctx.run_range([k]) for k in ks]),
-                     ("pooled, one fused launch", lambda: ctx.run_range(ks))):
+    variants = [("fixed quotas, one launch per iteration", None, lambda: [ctx.run_iteration(k) for k in ks]),
+                ("pooled, one launch per iteration", None, lambda: [ctx.run_range([k]) for k in ks])]
+    for ch in (256, 512, 1024, 2048):                                   # GFS_DBG_ONE_CHUNK: the chunk of a pooled launch of one iteration
+        variants.append((f"pooled, one launch per iteration, chunks of {ch}", str(ch), lambda: [ctx.run_range([k]) for k in ks]))
+    variants.append(("pooled, one fused launch", None, lambda: ctx.run_range(ks)))
+    for name, env, fn in variants:
+        os.environ.pop("GFS_DBG_ONE_CHUNK", None)
+        if env:
+            os.environ["GFS_DBG_ONE_CHUNK"] = env
         ctx.upload(x0)
         ctx.run_iteration(0)
         ctx.synchronize()
@@ -28,6 +34,6 @@ for dims in (0, 2):
         ctx.synchronize()
         s1 = ctx.stats()
         ms = (s1.kernel_ms - s0.kernel_ms) / len(ks)
-        print(f"D = {dims}  {name:40s}: {s1.launches - s0.launches:2d} launches, {ms * 1e3:8.1f} us of kernel per iteration = "
+        print(f"D = {dims}  {name:56s}: {s1.launches - s0.launches:2d} launches, {ms * 1e3:8.1f} us of kernel per iteration = "
               f"{(s1.term_updates - s0.term_updates) / len(ks) / (ms * 1e-3) / 1e9:6.1f} G updates/s", flush=True)
     ctx.close()

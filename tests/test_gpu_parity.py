@@ -778,35 +778,23 @@ def test_fused_layout_launch_equals_per_iteration_launches_on_one_wave(dims):
     assert np.array_equal(cf.view(np.uint64), cu.view(np.uint64))
 
 
-def _one_iteration_chunk(per_wave):
-    """capi.hip gfs_ctx_run_range: chunk of a pooled launch of ONE iteration (None: the launch keeps its fixed quotas)"""
-    chunk = 2048
-    while chunk > 256 and per_wave < 8 * chunk:
-        chunk >>= 1
-    return chunk if per_wave >= 4 * chunk else None
-
-
 @pytest.mark.parametrize("dims", [2, 3])
-def test_pooled_layout_launches_of_one_iteration_work_in_shorter_chunks_and_equal_the_mirror(dims):
-    """gfs_ctx_run_range with ONE layout iteration draws it from the pool in chunks short enough that every wave takes ~8 of them
-    (multi-GPU windows of one iteration; callers that step the schedule themselves).  One wave, iteration by iteration, against
-    the oracle's mirror told the same chunk: bit for bit."""
+def test_pooled_layout_launches_of_one_iteration_equal_the_mirror(dims):
+    """gfs_ctx_run_range with ONE layout iteration draws it from the pool where it is many chunks per wave (multi-GPU windows of
+    one iteration; callers that step the schedule themselves).  One wave, iteration by iteration, against the oracle's mirror:
+    bit for bit, and one launch each."""
     g = G.synth_windows(40_000, 8, 20_000, 12)
-    p = P.LayoutSGDParams.from_graph(g, dims, 1) if dims else P.YgsParams.from_graph(g, 0, 1).path_sgd
-    p.iter_max = 7
-    p.min_term_updates = 5_000                                   # one wave: 5000 updates per iteration -> chunks of 512
-    chunk = _one_iteration_chunk(p.min_term_updates)
-    assert chunk == 512
+    p = P.LayoutSGDParams.from_graph(g, dims, 1)
+    p.iter_max = 3
+    p.min_term_updates = 40_000                                  # one wave: 19.5 chunks of 2048 per iteration
     og, op = oracle_graph(g), oracle_params(p)
-    x0 = gaussian_init(g, dims, 5) if dims else hip.init_positions(g)
+    x0 = gaussian_init(g, dims, 5)
     x_ref = x0.copy()
-    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64, dims), partners=2,
-                   chunk=chunk)
+    st_o = O.State(og, op, dims=dims, n_streams=64, bundle=64, node_slots=_node_slots(g), chain=_mirror_chain(64, dims), partners=2)
     st_o.run(x_ref)
     so = st_o.stats()
     ctx = hip.Context(g)
-    cfg = hip.make_config(n_streams=64, flags=hip.F_BUNDLE(64))
-    ctx.setup_nd(p, cfg) if dims else ctx.setup_1d(p, cfg)
+    ctx.setup_nd(p, hip.make_config(n_streams=64, flags=hip.F_BUNDLE(64)))
     ctx.upload(x0)
     for k in range(p.iter_max + 1):
         ctx.run_range([k])
@@ -815,7 +803,7 @@ def test_pooled_layout_launches_of_one_iteration_work_in_shorter_chunks_and_equa
     x = ctx.download()
     ctx.close()
     assert hst.launches == p.iter_max + 1
-    assert (hst.term_updates, hst.attempts) == (so.term_updates, so.attempts) and hst.term_updates == 8 * 5_000
+    assert (hst.term_updates, hst.attempts) == (so.term_updates, so.attempts) and hst.term_updates == 4 * 40_000
     assert np.array_equal(x.view(np.uint64), np.ascontiguousarray(x_ref).ravel().view(np.uint64))
 
 
