@@ -869,7 +869,7 @@ static void fill_kargs(const gfs_ctx *c, gfs::KArgs &a) {
     a.partners = c->partners;
     a.dbg2 = 0;
     if (const char *e = std::getenv("GFS_DBG2")) a.dbg2 = (uint32_t)std::atol(e);
-    a.chunk = gfs::TEAM_CHUNK;
+    a.chunk = c->dims ? gfs::ND_TEAM_CHUNK : gfs::TEAM_CHUNK;
     a.ref_chunk = gfs::REF_CHUNK_PER_LANE;
     if (const char *e = std::getenv("GFS_DBG_REF_CHUNK")) { const long v = std::atol(e); if (v >= 1 && v <= 4096) a.ref_chunk = (uint32_t)v; }   // probe knob (scripts/ref_fused_probe.py)
     a.n_nodes = (uint32_t)c->n_nodes;
@@ -948,15 +948,15 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     const bool team_fusable = team_shape && (pool_ok || free_running) &&
                               (c->n_streams + c->block - 1) / c->block <= c->fused_resident_blocks;   // every workgroup resident
     const bool ref_fusable = c->bundle == 1 && pool_ok;
-    // A range of ONE layout iteration is drawn from the pool too where it is many chunks per wave: with fixed quotas a layout
+    // A range of ONE layout iteration is drawn from the pool too where it is at least four chunks per wave: with fixed quotas a layout
     // launch's waves finish as far apart as their leaders' costs are (C4: 2.33 ms per iteration against 2.21 pooled, 2.04 inside
     // a fused range).  Not with shorter chunks for smaller iterations: the layout pool is ONE counter, and it takes ~2e7 claims/s
     // comfortably and 4e7 not (C4 in chunks of 1024 / 512 / 256: 2.41 / 3.05 / 5.24 ms).  Not for the sort either: its launches of
     // one iteration are short (C3: 0.16 ms with fixed quotas, 0.15 pooled in chunks of 1024, 0.10 inside a fused range)
     // (profiles/r03/one_iteration_launch_probe.log, launch_overhead_probe.log).
-    uint32_t one_chunk = gfs::TEAM_CHUNK;
+    uint32_t one_chunk = c->dims ? gfs::ND_TEAM_CHUNK : gfs::TEAM_CHUNK;
     const uint64_t per_wave = c->quota_total / n_waves;
-    bool single_ok = team_fusable && pool_ok && c->dims != 0 && per_wave >= 8ull * one_chunk;
+    bool single_ok = team_fusable && pool_ok && c->dims != 0 && per_wave >= 4ull * one_chunk;
     if (const char *e = std::getenv("GFS_DBG_ONE_CHUNK")) {               // probe knob (scripts/one_iteration_launch_probe.py): also for the sort
         const long v = std::atol(e);
         if (v >= 64 && v <= 4096 && !(v & (v - 1))) { one_chunk = (uint32_t)v; single_ok = team_fusable && pool_ok; }
@@ -1001,6 +1001,10 @@ int gfs_ctx_run_range(gfs_ctx *c, const uint64_t *ks, uint64_t n, void *hip_stre
     gfs::KArgs a{};
     fill_kargs(c, a);
     if (n == 1 && c->bundle > 1) a.chunk = one_chunk;
+    if (const char *e = std::getenv("GFS_DBG_CHUNK")) {                    // probe knob: the chunk of every fused team launch
+        const long v = std::atol(e);
+        if (c->bundle > 1 && v >= 64 && v <= 16384 && !(v & (v - 1))) a.chunk = (uint32_t)v;
+    }
     iter_consts(c, ks[0], a.it);
     dim3 block(c->block), grid((unsigned)((c->n_streams + c->block - 1) / c->block));
     // work pools (sgd_kernels_1d.hip): the waves draw an iteration's updates from shared counters, zeroed per launch

@@ -275,6 +275,9 @@ __device__ __forceinline__ uint32_t leader_ok(uint32_t okw, uint32_t p) { return
 // A team wave works through an iteration in CHUNKS of this many updates (sgd_kernels_1d.hip, work pools); the rank cut-off
 // that makes a count exact applies at the end of every chunk.  2048 = 32 full trips.
 constexpr uint32_t TEAM_CHUNK = 2048;        // (the value of KArgs.chunk unless a probe says otherwise: capi.hip gfs_ctx_run_range)
+// ... and of this many in the layout kernels: their pool is ONE counter per iteration (sgd_kernels_nd_team.hip K2c), and half as many
+// claims are worth 3 % (C4: 49.5 -> 51.0 G updates/s; 8192: 50.8; profiles/r03/chunk_size_probe.log).  The sort is best at 2048.
+constexpr uint32_t ND_TEAM_CHUNK = 4096;
 
 // LONG RUNS.  A leader is expanded not over one trip but over K consecutive trips of its wave: trip `seg` takes the
 // steps seg*B .. seg*B+B-1 further along the path, all with the leader's jump, so a run is K*B consecutive steps.

@@ -766,6 +766,7 @@ static int term_nd_flips(const pidx *pi, const iter_state *it, int fa, int fb, u
 /* A leader: step a and one partner b — or, with two partners (product: sgd_device.h Leader, KArgs.partners = 2), the same
  * step a with two independent draws of b.  (ra0, rb0, ok, aligned, rot) is the partner a trip works on: partner_view. */
 #define GFO_TEAM_CHUNK 2048u
+#define GFO_ND_TEAM_CHUNK 4096u          /* product: sgd_device.h ND_TEAM_CHUNK (layout kernels) */
 typedef struct leader_s { uint64_t first, cnt, ra0, rb0; int ok, aligned, rot; uint64_t ra1, rb1; int ok1, aligned1, rot1; } leader_t;
 static leader_t partner_view(const leader_t *L, uint64_t p) {
     leader_t v = *L;
@@ -1135,7 +1136,7 @@ static int run_iteration_bundled(gfo_state *s, uint64_t k, double *x) {
         /* 1D: the wave works through its quota in chunks of GFO_TEAM_CHUNK updates, each with its own rank cut-off and pass
          * budget (product: sgd_device.h TEAM_CHUNK; its fused launch draws such chunks from a pool) */
         const uint64_t wave_quota_all = wave_quota;
-        const uint64_t CH = s->chunk ? s->chunk : GFO_TEAM_CHUNK;
+        const uint64_t CH = s->chunk ? s->chunk : (s->D ? GFO_ND_TEAM_CHUNK : GFO_TEAM_CHUNK);
         for (uint64_t chunk0 = 0; chunk0 < wave_quota_all; chunk0 += (carry ? CH : wave_quota_all)) {
         if (carry) wave_quota = wave_quota_all - chunk0 < CH ? wave_quota_all - chunk0 : CH;
         const uint64_t max_passes = s->attempt_factor * (wave_quota / (64 * B) + 1) + 16;

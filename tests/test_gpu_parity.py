@@ -786,7 +786,7 @@ def test_pooled_layout_launches_of_one_iteration_equal_the_mirror(dims):
     g = G.synth_windows(40_000, 8, 20_000, 12)
     p = P.LayoutSGDParams.from_graph(g, dims, 1)
     p.iter_max = 3
-    p.min_term_updates = 40_000                                  # one wave: 19.5 chunks of 2048 per iteration
+    p.min_term_updates = 40_000                                  # one wave: 9.8 chunks of 4096 per iteration
     og, op = oracle_graph(g), oracle_params(p)
     x0 = gaussian_init(g, dims, 5)
     x_ref = x0.copy()
