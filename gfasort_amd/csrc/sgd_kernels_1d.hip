@@ -312,30 +312,6 @@ __device__ __forceinline__ bool fused_trip(const KArgs &a, TeamState &ts, const 
 // both; the second term computes on what the first left in the register, as it would read it back from memory; a's node
 // takes ONE add, -(r + r'), b and c one each: 3 blocks of 8 requests for 128 updates where two trips take 4.  Returns false
 // when the wave's quota filled before the second term: the caller leaves the second partner's trip to the next iteration.
-// EXPERIMENT (GFS_DBG2 & 512): a run's terms with the part of their error that differs from the run's mean clipped at kappa
-// times its mean magnitude (kappa = bits 12..15, default 4) — the hypothesis being that a run copies the local distortion
-// pattern of one block onto the other, which single terms cannot.
-__device__ __forceinline__ double wave_sum_f64(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double term_move_clipped(const KArgs &a, bool valid, double term_dist, double xi, double xj, int crowd) {
-    double dx = xi - xj;
-    if (dx == 0.0) dx = 1e-9;
-    const double mag = fabs(dx);
-    const double s = valid ? mag - term_dist : 0.0;
-    const double n = wave_sum_f64(valid ? 1.0 : 0.0);
-    const double mean = n > 0.0 ? wave_sum_f64(s) / n : 0.0;
-    const double dl = valid ? s - mean : 0.0;
-    const double m = n > 0.0 ? wave_sum_f64(fabs(dl)) / n : 0.0;
-    const uint32_t kq = (a.dbg2 >> 12) & 15u;
-    const double lim = (kq ? (double)kq : 4.0) * m;
-    const double dc = dl > lim ? lim : (dl < -lim ? -lim : dl);
-    if (!valid) return 0.0;
-    const double mu = crowd_scale(fmin(a.it.eta * (1.0 / term_dist), 1.0), crowd);
-    const double delta = mu * (mean + dc) / 2.0;
-    return (delta / mag) * dx;
-}
 template <bool ATOMIC_LOADS, bool TRACE>
 __device__ __forceinline__ bool twin_trip(const KArgs &a, TeamState &ts, const Trip &cur, const int lane,
                                           const uint32_t tid, const uint64_t wave_quota, uint64_t &wave_done) {
@@ -362,11 +338,8 @@ __device__ __forceinline__ bool twin_trip(const KArgs &a, TeamState &ts, const T
         const uint32_t nvalid = (uint32_t)__popcll(vmask);
         if (valid && nvalid > remaining) valid = (uint32_t)__popcll(vmask & ((1ull << lane) - 1ull)) < remaining;
         wave_done += nvalid < remaining ? nvalid : remaining;
-        double r_clip = 0.0;
-        const bool clip = (a.dbg2 & 512u) != 0u;                                       // (wave-uniform; experiment)
-        if (clip) r_clip = term_move_clipped(a, valid, term_dist, xa, p ? xc : xb, crowd_shift<true>(a, cur.ra, rp));
         if (valid) {
-            const double r_x = clip ? r_clip : term_move(a, term_dist, xa, p ? xc : xb, crowd_shift<true>(a, cur.ra, rp));   // :518-571
+            const double r_x = term_move(a, term_dist, xa, p ? xc : xb, crowd_shift<true>(a, cur.ra, rp));   // :518-571
             ++ts.done;                                                                 // :579
             if (TRACE) {
                 if (ts.ntr < a.trace_per_stream) {

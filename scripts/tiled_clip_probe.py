@@ -1,4 +1,5 @@
-"""EXPERIMENT: DRB1-3123 x120 (-p Y --iter-max 100) and the 525k-node bubble graph with the differential part of a twin trip's
+"""EXPERIMENT (needs the kernel code of the commit "Experiment: clipping the differential part ..."; the current library
+ignores GFS_DBG2): DRB1-3123 x120 (-p Y --iter-max 100) and the 525k-node bubble graph with the differential part of a twin trip's
 errors clipped (GFS_DBG2 = 512 | kappa << 12).   python scripts/tiled_clip_probe.py"""
 import os
 import sys
