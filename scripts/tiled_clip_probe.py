@@ -16,9 +16,12 @@ for title, g in (("DRB1-3123 x120", G.tile_series(load("DRB1-3123.gfa"), 120)), 
     og = oracle_graph(g)
     p = P.YgsParams.from_graph(g, 0, 1).path_sgd
     print(f"{title}, -p Y --iter-max 100; columns: G upd/s | stress 2M | rel. error at path distance 1, 2-3, ... 512-1023 | d1 trimmed | RMSE bp", flush=True)
-    for name, flags, dbg2 in (("reference streams", hip.F_BUNDLE(1), 0), ("default", 0, 0), ("default", 0, 0), ("clip kappa 1", 0, 512 | (1 << 12)),
-                              ("clip kappa 2", 0, 512 | (2 << 12)), ("clip kappa 4", 0, 512 | (4 << 12)), ("clip kappa 4", 0, 512 | (4 << 12)),
-                              ("clip kappa 8", 0, 512 | (8 << 12))):
+    VAR = (("reference streams", hip.F_BUNDLE(1), 0), ("default", 0, 0), ("default", 0, 0), ("clip kappa 1", 0, 512 | (1 << 12)),
+           ("clip kappa 2", 0, 512 | (2 << 12)), ("clip kappa 4", 0, 512 | (4 << 12)), ("clip kappa 4", 0, 512 | (4 << 12)), ("clip kappa 8", 0, 512 | (8 << 12)))
+    if "--permute" in sys.argv:
+        VAR = (("reference streams", hip.F_BUNDLE(1), 0), ("default", 0, 0), ("default", 0, 0), ("partners permuted", 0, 1024), ("partners permuted", 0, 1024),
+               ("partners permuted", 0, 1024))
+    for name, flags, dbg2 in VAR:
         os.environ["GFS_DBG2"] = str(dbg2)
         ctx = hip.Context(g)
         ctx.setup_1d(p, hip.make_config(flags=flags)); ctx.init_positions(); ctx.run()
