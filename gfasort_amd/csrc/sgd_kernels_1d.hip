@@ -193,16 +193,9 @@ __device__ __forceinline__ void expand_trip(const KArgs &a, const Leader &L, int
         if (gap < lim && gap > -lim) tr.twin = false;
     }
     if (tr.twin) {
-        // EXPERIMENT (GFS_DBG2 & 1024): lane l is paired with the partner block's step pi(l), pi = l XOR m with m drawn per trip
-        // and partner — the same blocks, the same lines, but neighbouring steps of the a-run no longer take neighbouring partners
-        uint32_t mb = 0u, mc = 0u;
-        if (a.dbg2 & 1024u) {
-            mb = ((ra0 + rb0 + seg * 0x9E37u) * 2654435761u) >> 26;
-            mc = ((ra0 + rb1 + seg * 0x7F4Au + 0x51EDu) * 2246822519u) >> 26;
-        }
         tr.sa = first + ra0 + tr.off + (uint32_t)sub;
-        tr.sb = first + rb0 + tr.off + ((((uint32_t)sub ^ mb) + ((okw >> 2) & 7u)) & 63u);
-        const uint64_t sc = first + rb1 + tr.off + ((((uint32_t)sub ^ mc) + ((okw >> 10) & 7u)) & 63u);
+        tr.sb = first + rb0 + tr.off + (((uint32_t)sub + ((okw >> 2) & 7u)) & 63u);
+        const uint64_t sc = first + rb1 + tr.off + (((uint32_t)sub + ((okw >> 10) & 7u)) & 63u);
         tr.valid = true;
         tr.ra = a.step_rec[tr.sa]; tr.rb = a.step_rec[tr.sb]; tr.rc = a.step_rec[sc];
         return;
