@@ -559,7 +559,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) sgd1d_team_kernel(con
 // (one returning atomic per chunk, on one of up to 16 counters — one per 16 waves, sgd_kernel_common.h pool_slots — so that the
 // claims do not queue on one address; a wave
 // claims its next chunk before it works on the current one).  A wave moves on to iteration k + 1 when its counter of
-// iteration k is exhausted: no wave is ever more than two chunks away from the others, nobody waits, and a wave that is
+// iteration k is exhausted: no wave is ever more than two chunks away from the others OF ITS COUNTER (the counters are fixed
+// shares of an iteration: the waves of a fast one can run ahead of a slow one's — harmless for the sort, whose figures are the
+// same with a launch per iteration; the layout kernel, K2c, uses one counter), nobody waits, and a wave that is
 // slow simply takes fewer chunks — which is the reference's own rule (its workers share one count per iteration).  Every
 // iteration still applies exactly min_term_updates updates with its own eta/theta.  C3: 97.8 G updates/s.
 // (A single wave claims every chunk itself, in order: the kernel with fixed quotas works through its quota in the same
